@@ -1,0 +1,17 @@
+"""MI355X-native multi-scalar multiplication behind the ZPrize-2022 prize1-msm operator API.
+
+The directory name (``2022-entries_amd``) is not a Python identifier; import it through the
+``entries_amd`` shim at the repo root (``import entries_amd``), which loads this package.
+"""
+from .msm import (  # noqa: F401
+    CURVE_IDS,
+    MsmError,
+    MultiScalarMultContext,
+    VariableBaseMSM,
+    fold_partials,
+    library_path,
+    load_library,
+    multi_scalar_mult,
+    multi_scalar_mult_init,
+    msm,
+)

@@ -1,0 +1,295 @@
+// fp28.cuh -- 384-bit prime-field arithmetic for gfx950, unsaturated radix-2^28 limbs.
+//
+// Why this shape (measured on MI355X, tools/ubench_valu.hip, profiles/r01_ubench_valu.txt):
+// v_mad_u64_u32 issues at the same ~4.3 cycles/wave as v_addc_co_u32, and gfx950 needs two wait
+// states between a VALU that writes a carry (VCC/SGPR) and the VALU that consumes it.  A saturated
+// 12x32-bit Montgomery product therefore costs a carry instruction (plus hazard padding) per
+// multiply-add.  With 14 limbs of 28 bits every partial product is < 2^60, a whole product-scanning
+// column (<= 14 a*b terms + 14 m*p terms) fits a 64-bit accumulator, and the multiplication is one
+// dependent chain of v_mad_u64_u32 with NO carry instructions.  Additions and subtractions are
+// limb-wise (no carry chain either); values are kept lazily reduced and only bounded, see below.
+//
+// The same header compiles for the host (plain C++), which is how tests/ check the limb-bound
+// analysis (MSM_CHECK) and how the host-side window fold (host_fold.cpp) shares the arithmetic.
+//
+// Reference behaviour being re-implemented (not translated): sppark mont_t mul/add/sub
+// (SPK ff/mont_t.cuh:385-425, 187-212, 278-299) and Matter Labs' lazily reduced field
+// (ML ff_dispatch_st.cuh:234-481).  The ABI Montgomery radix (2^384) is converted at the
+// boundary with CIN/COUT.
+//
+// Representation.  value(a) = sum a.v[i] * 2^(28 i), Montgomery form x*R mod p with R = 2^392.
+//   "normalized": v[0..12] < 2^28 (v[13] holds what is left).
+//   mul inputs: every limb < 2^30 and value(a)*value(b) <= 2^10 p^2 (e.g. both values < 32p).
+//   class M ("mul output"): normalized, value < p + a*b/R < 1.5p  (2^10 p^2 / 2^392 < p/2 for p < 2^381).
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define MSM_HD __host__ __device__ __forceinline__
+#else
+#define MSM_HD inline
+#endif
+
+#ifndef MSM_CHECK
+#define MSM_CHECK(cond) ((void)0)
+#endif
+
+namespace msm {
+
+constexpr int NL = 14;
+constexpr int LB = 28;
+constexpr uint32_t LMASK = 0x0fffffffu;
+
+#include "field_consts.inc"
+
+struct Fe {
+  uint32_t v[NL];
+};
+
+// Keep a modulus limb in a scalar register and opaque to the optimiser, so that m*p[j] stays a
+// single v_mad_u64_u32 with an SGPR operand instead of being strength-reduced into shift/add chains.
+MSM_HD uint32_t opaque_u32(uint32_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm("" : "+s"(x));
+#endif
+  return x;
+}
+
+template <class F>
+struct Modulus {
+  uint32_t p[NL];
+  MSM_HD Modulus() {
+#pragma unroll
+    for (int i = 0; i < NL; i++) p[i] = opaque_u32(F::P[i]);
+  }
+};
+
+MSM_HD void fe_set(Fe& r, const uint32_t (&c)[NL]) {
+#pragma unroll
+  for (int i = 0; i < NL; i++) r.v[i] = c[i];
+}
+
+MSM_HD void fe_zero(Fe& r) {
+#pragma unroll
+  for (int i = 0; i < NL; i++) r.v[i] = 0;
+}
+
+// r = a*b*R^-1 (mod p), class M.  Product scanning: column k gathers every a_i*b_j and m_i*p_j with
+// i+j = k in ONE 64-bit accumulator; m_k clears the low 28 bits and the column is shifted down.
+// Bound: limbs < 2^30  =>  14*(2^30)^2 + 14*(2^28)^2 + carry < 2^64.
+template <class F>
+MSM_HD void fe_mul(Fe& r, const Fe& a, const Fe& b, const Modulus<F>& md) {
+  uint32_t m[NL];
+  Fe t;
+  uint64_t col = 0;
+#pragma unroll
+  for (int i = 0; i < NL; i++) {
+    MSM_CHECK(a.v[i] < (1u << 30) && b.v[i] < (1u << 30));
+  }
+#pragma unroll
+  for (int k = 0; k < NL; k++) {
+#pragma unroll
+    for (int i = 0; i <= k; i++) col += (uint64_t)a.v[i] * b.v[k - i];
+#pragma unroll
+    for (int i = 0; i < k; i++) col += (uint64_t)m[i] * md.p[k - i];
+    m[k] = ((uint32_t)col * F::M0) & LMASK;
+    col += (uint64_t)m[k] * md.p[0];
+    MSM_CHECK(((uint32_t)col & LMASK) == 0);
+    col >>= LB;
+  }
+#pragma unroll
+  for (int k = NL; k < 2 * NL - 1; k++) {
+#pragma unroll
+    for (int i = k - NL + 1; i < NL; i++) col += (uint64_t)a.v[i] * b.v[k - i];
+#pragma unroll
+    for (int i = k - NL + 1; i < NL; i++) col += (uint64_t)m[i] * md.p[k - i];
+    t.v[k - NL] = (uint32_t)col & LMASK;
+    col >>= LB;
+  }
+  MSM_CHECK(col < (1ull << 28));
+  t.v[NL - 1] = (uint32_t)col;
+  r = t;
+}
+
+template <class F>
+MSM_HD void fe_sqr(Fe& r, const Fe& a, const Modulus<F>& md) {
+  fe_mul<F>(r, a, a, md);
+}
+
+// Limb-wise r = a + b.  Caller tracks bounds (limbs add, values add).
+MSM_HD void fe_add(Fe& r, const Fe& a, const Fe& b) {
+#pragma unroll
+  for (int i = 0; i < NL; i++) r.v[i] = a.v[i] + b.v[i];
+}
+
+MSM_HD void fe_dbl(Fe& r, const Fe& a) {
+#pragma unroll
+  for (int i = 0; i < NL; i++) r.v[i] = a.v[i] << 1;
+}
+
+// Limb-wise r = a + (k*p lifted) - b.  `bias` is one of F::BIASk_l: k*p with each limb raised by
+// 2^l, so no limb underflows when b's limbs are <= 2^l and value(b) <= k*p.  value(r) = a + k*p - b.
+MSM_HD void fe_sub(Fe& r, const Fe& a, const Fe& b, const uint32_t (&bias)[NL]) {
+#pragma unroll
+  for (int i = 0; i < NL; i++) {
+    MSM_CHECK(bias[i] >= b.v[i]);
+    MSM_CHECK((uint64_t)a.v[i] + bias[i] - b.v[i] < (1ull << 32));
+    r.v[i] = a.v[i] + (bias[i] - b.v[i]);
+  }
+}
+
+// r = (k*p) - b  (negation, value in (0, k*p]).
+MSM_HD void fe_neg(Fe& r, const Fe& b, const uint32_t (&bias)[NL]) {
+#pragma unroll
+  for (int i = 0; i < NL; i++) {
+    MSM_CHECK(bias[i] >= b.v[i]);
+    r.v[i] = bias[i] - b.v[i];
+  }
+}
+
+// One parallel carry pass: every limb keeps its low 28 bits and receives its lower neighbour's
+// overflow.  Limbs up to 2^32-1 come out < 2^28 + 16; the value is unchanged.
+MSM_HD void fe_carry(Fe& r) {
+  uint32_t c[NL - 1];
+#pragma unroll
+  for (int i = 0; i < NL - 1; i++) c[i] = r.v[i] >> LB;
+  r.v[0] &= LMASK;
+#pragma unroll
+  for (int i = 1; i < NL - 1; i++) r.v[i] = (r.v[i] & LMASK) + c[i - 1];
+  r.v[NL - 1] += c[NL - 2];
+}
+
+// Sequential carry propagation to strictly normalized limbs (v[0..12] < 2^28).
+MSM_HD void fe_normalize(Fe& r) {
+  uint32_t c = 0;
+#pragma unroll
+  for (int i = 0; i < NL - 1; i++) {
+    uint32_t t = r.v[i] + c;
+    r.v[i] = t & LMASK;
+    c = t >> LB;
+  }
+  r.v[NL - 1] += c;
+}
+
+// a >= b on strictly normalized limbs.
+MSM_HD bool fe_geq(const Fe& a, const uint32_t (&b)[NL]) {
+  bool ge = true;  // equal so far => a >= b
+#pragma unroll
+  for (int i = 0; i < NL; i++) {
+    if (a.v[i] != b[i]) ge = a.v[i] > b[i];
+  }
+  return ge;
+}
+
+// Canonical representative in [0, p), strictly normalized.  Input: limbs < 2^31, value < 64p.  Slow path
+// (zero tests in rare branches, final output); the hot loop never calls it.
+template <class F>
+MSM_HD void fe_reduce(Fe& r) {
+  fe_normalize(r);
+#pragma unroll 1
+  for (int k = 32; k >= 1; k >>= 1) {
+    // subtract k*p if r >= k*p
+    uint32_t kp[NL];
+    uint64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+      c += (uint64_t)F::P[i] * (uint32_t)k;
+      kp[i] = (i == NL - 1) ? (uint32_t)c : ((uint32_t)c & LMASK);
+      c >>= LB;
+    }
+    if (fe_geq(r, kp)) {
+      int32_t borrow = 0;
+#pragma unroll
+      for (int i = 0; i < NL; i++) {
+        int64_t d = (int64_t)r.v[i] - kp[i] + borrow;
+        if (i < NL - 1) {
+          r.v[i] = (uint32_t)d & LMASK;
+          borrow = (int32_t)(d >> LB);
+        } else {
+          r.v[i] = (uint32_t)d;
+        }
+      }
+    }
+  }
+}
+
+// value == 0 (mod p) for a class-M element (normalized, < 2p): it is 0 or p.  The first-limb test
+// rejects all but ~2^-27 of the non-zero values, so the full compare is off the hot path.
+template <class F>
+MSM_HD bool fe_is_zero_M(const Fe& a) {
+  if (a.v[0] != 0 && a.v[0] != F::P[0]) return false;
+  uint32_t z = 0, e = 0;
+#pragma unroll
+  for (int i = 0; i < NL; i++) {
+    z |= a.v[i];
+    e |= a.v[i] ^ F::P[i];
+  }
+  return z == 0 || e == 0;
+}
+
+// General zero test (any bounded lazy value).
+template <class F>
+MSM_HD bool fe_is_zero_slow(const Fe& a) {
+  Fe t = a;
+  fe_reduce<F>(t);
+  uint32_t z = 0;
+#pragma unroll
+  for (int i = 0; i < NL; i++) z |= t.v[i];
+  return z == 0;
+}
+
+MSM_HD void fe_cmov(Fe& r, const Fe& a, bool take) {
+#pragma unroll
+  for (int i = 0; i < NL; i++) r.v[i] = take ? a.v[i] : r.v[i];
+}
+
+// ---- ABI conversions (6 x u64 little-endian, Montgomery radix 2^384  <->  internal) ----------
+
+// 48 bytes (12 u32 words, little-endian) -> radix-2^28 limbs of the same integer.
+MSM_HD void fe_from_words(Fe& r, const uint32_t* w) {
+#pragma unroll
+  for (int i = 0; i < NL; i++) {
+    int bit = LB * i;
+    int wi = bit >> 5, sh = bit & 31;
+    uint64_t lo = (wi < 12) ? w[wi] : 0;
+    uint64_t hi = (wi + 1 < 12) ? w[wi + 1] : 0;
+    r.v[i] = (uint32_t)(((lo | (hi << 32)) >> sh)) & LMASK;
+  }
+}
+
+// strictly normalized limbs with value < 2^384 -> 12 u32 words.
+MSM_HD void fe_to_words(uint32_t* w, const Fe& a) {
+#pragma unroll
+  for (int j = 0; j < 12; j++) {
+    int bit = 32 * j;
+    int li = bit / LB, sh = bit % LB;
+    uint64_t acc = (uint64_t)a.v[li] >> sh;
+    int have = LB - sh;
+    if (li + 1 < NL) acc |= (uint64_t)a.v[li + 1] << have;
+    have += LB;
+    if (have < 32 && li + 2 < NL) acc |= (uint64_t)a.v[li + 2] << have;
+    w[j] = (uint32_t)acc;
+  }
+}
+
+// ABI Montgomery (x*2^384 mod p, canonical) -> internal class M (x*2^392 mod p).
+template <class F>
+MSM_HD void fe_from_abi(Fe& r, const uint32_t* w, const Modulus<F>& md) {
+  Fe t, c;
+  fe_from_words(t, w);
+  fe_set(c, F::CIN);
+  fe_mul<F>(r, t, c, md);
+}
+
+// internal lazy value (limbs < 2^30, value < 32p) -> canonical ABI Montgomery words.
+template <class F>
+MSM_HD void fe_to_abi(uint32_t* w, const Fe& a, const Modulus<F>& md) {
+  Fe t, c;
+  fe_set(c, F::COUT);
+  fe_mul<F>(t, a, c, md);
+  fe_reduce<F>(t);
+  fe_to_words(w, t);
+}
+
+}  // namespace msm

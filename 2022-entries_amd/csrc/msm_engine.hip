@@ -1,0 +1,507 @@
+// msm_engine.hip -- host orchestration of the MI355X MSM pipeline and the C ABI (include/mi355_msm.h).
+//
+// Role in the reference: the L1 "host orchestration" + L2 "C-ABI" layers of SURVEY.md section 1
+// (SPK msm/pippenger.cuh:247-662 pippenger_t, CMB MSM.cu:149-532 MSMContext, ML msm.cu:97-468).
+// One context = one device, one stream; bases are converted once and stay resident in HBM; a run is
+//   digits -> radix sort by (window, bucket) -> accumulate -> fragment merge -> bucket reduce -> host fold.
+// Everything is enqueued on one stream with no host round-trip until the W window sums (W * 224 B) come back.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string.h>
+
+#include <rocprim/rocprim.hpp>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/mi355_msm.h"
+#include "host_curve.hpp"
+#include "msm_kernels.cuh"
+
+namespace {
+
+using namespace msm;
+
+struct HipFailure : std::runtime_error {
+  int code;
+  HipFailure(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+#define HIP_OK(expr)                                                                                   \
+  do {                                                                                                 \
+    hipError_t e_ = (expr);                                                                            \
+    if (e_ != hipSuccess) {                                                                            \
+      char buf_[512];                                                                                  \
+      snprintf(buf_, sizeof buf_, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+      throw HipFailure((int)e_, buf_);                                                                 \
+    }                                                                                                  \
+  } while (0)
+
+[[noreturn]] void bad_arg(const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  throw HipFailure(-1, buf);
+}
+
+RustError ok() { return RustError{0, nullptr}; }
+
+RustError fail(int code, const char* msg) {
+  RustError e;
+  e.code = code ? code : -1;
+  e.message = strdup(msg ? msg : "unknown error");
+  return e;
+}
+
+template <class Fn>
+RustError guarded(Fn&& fn) {
+  try {
+    fn();
+    return ok();
+  } catch (const HipFailure& e) {
+    return fail(e.code, e.what());
+  } catch (const std::exception& e) {
+    return fail(-1, e.what());
+  } catch (...) {
+    return fail(-1, "unknown C++ exception");
+  }
+}
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+  void reserve(size_t need) {
+    if (need <= bytes) return;
+    release();
+    HIP_OK(hipMalloc(&p, need));
+    bytes = need;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+  }
+  template <class T>
+  T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+inline uint32_t ceil_div(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
+inline uint32_t ilog2_floor(uint64_t v) { uint32_t r = 0; while (v >>= 1) r++; return r; }
+
+// Window size: minimise  windows * (n mixed adds * 10 mul  +  2^(c-1) buckets * 3 full adds * 14 mul).
+int choose_window_bits(size_t n) {
+  int best = 2;
+  double best_cost = 1e300;
+  for (int c = 2; c <= 23; c++) {
+    double windows = (257 + c - 1) / c;
+    double cost = windows * ((double)n * 10.0 + (double)(1ull << (c - 1)) * 42.0);
+    if (cost < best_cost) { best_cost = cost; best = c; }
+  }
+  return best;
+}
+
+struct Plan {
+  uint32_t c, windows, half, sentinel, keybits;
+  uint64_t entries;     // windows * n
+  uint32_t K, nlanes;   // accumulate geometry
+  uint32_t segK;        // fragment-merge fan-in
+  uint32_t logL0, logL; // bucket-reduce chunk sizes
+  uint32_t T0;          // chunks per window on the first reduce level
+};
+
+}  // namespace
+
+struct mi355_msm_ctx {
+  int curve = 0;
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  size_t nbases = 0;
+  DevBuf bases, inf;
+  DevBuf scalars, keys[2], vals[2], sort_tmp, buckets, slots[2], slot_keys[2], red_a[2], red_x[2];
+  void* pinned = nullptr;  // window sums land here
+  size_t pinned_bytes = 0;
+  hipEvent_t ev[8] = {};
+  long opt_window_bits = 0, opt_lane_entries = 0, opt_max_chunk = 0, opt_seg_entries = 0;
+  float last_ms[MI355_T_COUNT] = {};
+  uint64_t last_info[8] = {};
+
+  Plan plan(size_t n) const {
+    Plan p{};
+    p.c = opt_window_bits ? (uint32_t)opt_window_bits : (uint32_t)choose_window_bits(n);
+    p.windows = (257 + p.c - 1) / p.c;
+    p.half = 1u << (p.c - 1);
+    p.sentinel = p.windows * p.half;
+    p.keybits = ilog2_floor(p.sentinel) + 1;
+    p.entries = (uint64_t)p.windows * n;
+    uint32_t K = opt_lane_entries ? (uint32_t)opt_lane_entries : (uint32_t)std::min<uint64_t>(128, std::max<uint64_t>(8, p.entries >> 20));
+    p.K = (K + 3) & ~3u;
+    p.nlanes = ceil_div(p.entries, p.K);
+    p.segK = opt_seg_entries ? (uint32_t)opt_seg_entries : 8;
+    uint64_t nb = (uint64_t)p.windows * p.half;
+    uint32_t l0 = nb > (1u << 18) ? ilog2_floor(nb >> 18) : 0;
+    p.logL0 = std::min<uint32_t>(7, std::max<uint32_t>(3, l0));
+    p.logL0 = std::min<uint32_t>(p.logL0, p.c - 1 ? p.c - 1 : 1);
+    p.logL = 3;
+    p.T0 = ceil_div(p.half, 1u << p.logL0);
+    return p;
+  }
+};
+
+namespace {
+
+void ensure_device(mi355_msm_ctx* ctx) { HIP_OK(hipSetDevice(ctx->device)); }
+
+template <class F>
+void convert_bases(mi355_msm_ctx* ctx, const uint8_t* d_raw, size_t n, size_t stride, hipStream_t st) {
+  ctx->bases.reserve(n * sizeof(AffineDev));
+  ctx->inf.reserve(n);
+  hipLaunchKernelGGL((k_convert_bases<F>), dim3(ceil_div(n, 256)), dim3(256), 0, st, d_raw, stride, (uint32_t)n,
+                     ctx->bases.as<AffineDev>(), ctx->inf.as<uint8_t>());
+  HIP_OK(hipGetLastError());
+}
+
+void set_bases_device(mi355_msm_ctx* ctx, const void* d_affine, size_t n, size_t stride) {
+  ensure_device(ctx);
+  if (stride < 97 || (stride & 3)) bad_arg("affine stride %zu is not a 4-byte multiple >= 97", stride);
+  if (n >= (1ull << 31)) bad_arg("npoints %zu exceeds 2^31-1", n);
+  if (n) {
+    if (ctx->curve == MI355_BLS12_377_G1)
+      convert_bases<Bls12_377_Fq>(ctx, (const uint8_t*)d_affine, n, stride, ctx->own_stream);
+    else
+      convert_bases<Bls12_381_Fq>(ctx, (const uint8_t*)d_affine, n, stride, ctx->own_stream);
+    HIP_OK(hipStreamSynchronize(ctx->own_stream));
+  }
+  ctx->nbases = n;
+}
+
+template <class F>
+void launch_accumulate(const Plan& p, const uint32_t* keys, const uint32_t* vals, const AffineDev* bases, SegOut out,
+                       hipStream_t st) {
+  hipLaunchKernelGGL((k_accumulate<F>), dim3(ceil_div(p.nlanes, 256)), dim3(256), 0, st, keys, vals, (uint32_t)p.entries,
+                     p.K, p.sentinel, bases, out, p.nlanes);
+  HIP_OK(hipGetLastError());
+}
+
+template <class F>
+void launch_segreduce(const XyzzDev* in_slots, const uint32_t* in_keys, uint32_t n_in, uint32_t K, SegOut out,
+                      uint32_t nlanes, hipStream_t st) {
+  hipLaunchKernelGGL((k_segreduce<F>), dim3(ceil_div(nlanes, 256)), dim3(256), 0, st, in_slots, in_keys, n_in, K, out, nlanes);
+  HIP_OK(hipGetLastError());
+}
+
+template <class F>
+void launch_bucket_reduce(bool first, const XyzzDev* in_a, const XyzzDev* in_x, uint32_t n_per_win, uint32_t logL,
+                          uint32_t chunks, uint32_t windows, XyzzDev* out_a, XyzzDev* out_x, hipStream_t st) {
+  dim3 grid(ceil_div((uint64_t)windows * chunks, 256));
+  if (first)
+    hipLaunchKernelGGL((k_bucket_reduce<F, true>), grid, dim3(256), 0, st, in_a, in_x, n_per_win, logL, chunks, windows, out_a, out_x);
+  else
+    hipLaunchKernelGGL((k_bucket_reduce<F, false>), grid, dim3(256), 0, st, in_a, in_x, n_per_win, logL, chunks, windows, out_a, out_x);
+  HIP_OK(hipGetLastError());
+}
+
+// One chunk of one batch: device scalars [0, n) against bases [base0, base0 + n).  Leaves the folded chunk sum in `out`.
+template <class F>
+void run_chunk(mi355_msm_ctx* ctx, const uint32_t* d_scalars, size_t base0, size_t n, hipStream_t st, Xyzz& out) {
+  const Plan p = ctx->plan(n);
+  if (p.entries >= (1ull << 32)) bad_arg("chunk of %zu pairs needs %llu sort entries (>= 2^32)", n, (unsigned long long)p.entries);
+  const size_t E = p.entries;
+  for (int i = 0; i < 2; i++) {
+    ctx->keys[i].reserve(E * 4);
+    ctx->vals[i].reserve(E * 4);
+  }
+  const size_t nbuckets = (size_t)p.windows * p.half;
+  ctx->buckets.reserve(nbuckets * sizeof(XyzzDev));
+  const size_t nslots0 = 2 * (size_t)p.nlanes;
+  for (int i = 0; i < 2; i++) {
+    ctx->slots[i].reserve(nslots0 * sizeof(XyzzDev));
+    ctx->slot_keys[i].reserve(nslots0 * 4);
+  }
+  const size_t red0 = (size_t)p.windows * p.T0;
+  for (int i = 0; i < 2; i++) {
+    ctx->red_a[i].reserve(red0 * sizeof(XyzzDev));
+    ctx->red_x[i].reserve(red0 * sizeof(XyzzDev));
+  }
+  if (ctx->pinned_bytes < p.windows * sizeof(XyzzDev)) {
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    ctx->pinned_bytes = 64 * sizeof(XyzzDev) > p.windows * sizeof(XyzzDev) ? 64 * sizeof(XyzzDev) : p.windows * sizeof(XyzzDev);
+    HIP_OK(hipHostMalloc(&ctx->pinned, ctx->pinned_bytes, hipHostMallocDefault));
+  }
+
+  rocprim::double_buffer<uint32_t> kbuf(ctx->keys[0].as<uint32_t>(), ctx->keys[1].as<uint32_t>());
+  rocprim::double_buffer<uint32_t> vbuf(ctx->vals[0].as<uint32_t>(), ctx->vals[1].as<uint32_t>());
+  size_t tmp_bytes = 0;
+  HIP_OK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, kbuf, vbuf, E, 0, p.keybits, st));
+  ctx->sort_tmp.reserve(tmp_bytes ? tmp_bytes : 16);
+
+  const AffineDev* bases = ctx->bases.as<AffineDev>() + base0;
+  const uint8_t* inf = ctx->inf.as<uint8_t>() + base0;
+
+  HIP_OK(hipEventRecord(ctx->ev[0], st));
+  hipLaunchKernelGGL(k_digits, dim3(ceil_div(n, 256)), dim3(256), 0, st, d_scalars, inf, (uint32_t)n, p.c, p.windows,
+                     kbuf.current(), vbuf.current());
+  HIP_OK(hipGetLastError());
+  HIP_OK(hipEventRecord(ctx->ev[1], st));
+  HIP_OK(rocprim::radix_sort_pairs(ctx->sort_tmp.p, tmp_bytes, kbuf, vbuf, E, 0, p.keybits, st));
+  HIP_OK(hipMemsetAsync(ctx->buckets.p, 0, nbuckets * sizeof(XyzzDev), st));
+  HIP_OK(hipEventRecord(ctx->ev[2], st));
+
+  SegOut so{ctx->buckets.as<XyzzDev>(), ctx->slots[0].as<XyzzDev>(), ctx->slot_keys[0].as<uint32_t>()};
+  launch_accumulate<F>(p, kbuf.current(), vbuf.current(), bases, so, st);
+  HIP_OK(hipEventRecord(ctx->ev[3], st));
+
+  // merge the run fragments that crossed lane boundaries
+  uint32_t n_in = 2 * p.nlanes;
+  int cur = 0;
+  if (p.nlanes > 1) {
+    for (;;) {
+      uint32_t nl = ceil_div(n_in, p.segK);
+      SegOut o{ctx->buckets.as<XyzzDev>(), ctx->slots[cur ^ 1].as<XyzzDev>(), ctx->slot_keys[cur ^ 1].as<uint32_t>()};
+      launch_segreduce<F>(ctx->slots[cur].as<XyzzDev>(), ctx->slot_keys[cur].as<uint32_t>(), n_in, p.segK, o, nl, st);
+      if (nl == 1) break;
+      n_in = 2 * nl;
+      cur ^= 1;
+    }
+  }
+  HIP_OK(hipEventRecord(ctx->ev[4], st));
+
+  // buckets -> one point per window
+  uint32_t n_per_win = p.half, logL = p.logL0, chunks = p.T0;
+  int rb = 0;
+  launch_bucket_reduce<F>(true, nullptr, ctx->buckets.as<XyzzDev>(), n_per_win, logL, chunks, p.windows,
+                          ctx->red_a[0].as<XyzzDev>(), ctx->red_x[0].as<XyzzDev>(), st);
+  while (chunks > 1) {
+    n_per_win = chunks;
+    logL = p.logL;
+    chunks = ceil_div(n_per_win, 1u << logL);
+    launch_bucket_reduce<F>(false, ctx->red_a[rb].as<XyzzDev>(), ctx->red_x[rb].as<XyzzDev>(), n_per_win, logL, chunks,
+                            p.windows, ctx->red_a[rb ^ 1].as<XyzzDev>(), ctx->red_x[rb ^ 1].as<XyzzDev>(), st);
+    rb ^= 1;
+  }
+  HIP_OK(hipEventRecord(ctx->ev[5], st));
+  HIP_OK(hipMemcpyAsync(ctx->pinned, ctx->red_a[rb].p, p.windows * sizeof(XyzzDev), hipMemcpyDeviceToHost, st));
+  HIP_OK(hipEventRecord(ctx->ev[6], st));
+  HIP_OK(hipStreamSynchronize(st));
+
+  Modulus<F> md;
+  std::vector<Xyzz> sums(p.windows);
+  const XyzzDev* hs = reinterpret_cast<const XyzzDev*>(ctx->pinned);
+  for (uint32_t w = 0; w < p.windows; w++) sums[w] = hs[w].p;
+  fold_windows<F>(out, sums.data(), (int)p.windows, (int)p.c, md);
+
+  float ms = 0;
+  for (int s = 0; s < 5; s++) {
+    HIP_OK(hipEventElapsedTime(&ms, ctx->ev[s], ctx->ev[s + 1]));
+    ctx->last_ms[s] += ms;
+  }
+  HIP_OK(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[6]));
+  ctx->last_ms[MI355_T_TOTAL] += ms;
+  ctx->last_info[0] = p.c;
+  ctx->last_info[1] = p.windows;
+  ctx->last_info[2] = E;
+  ctx->last_info[3] = p.K;
+  ctx->last_info[4] += 1;
+  ctx->last_info[5] = p.nlanes;
+}
+
+template <class F>
+void run_device_t(mi355_msm_ctx* ctx, uint8_t* out, const uint32_t* d_scalars, size_t n, size_t batches, hipStream_t st) {
+  Modulus<F> md;
+  const size_t max_chunk = ctx->opt_max_chunk ? (size_t)ctx->opt_max_chunk : ((size_t)1 << 26);
+  for (size_t b = 0; b < batches; b++) {
+    Xyzz total;
+    xyzz_set_inf<F>(total);
+    for (size_t off = 0; off < n; off += max_chunk) {
+      size_t cn = std::min(max_chunk, n - off);
+      Xyzz part;
+      run_chunk<F>(ctx, d_scalars + (b * n + off) * 8, off, cn, st, part);
+      xyzz_add<F>(total, part, md);
+    }
+    xyzz_to_projective_abi<F>(out + b * 144, total, md);
+  }
+}
+
+void run_device(mi355_msm_ctx* ctx, void* out, const void* d_scalars, size_t n, size_t batches, hipStream_t st) {
+  ensure_device(ctx);
+  if (n > ctx->nbases) bad_arg("npoints %zu exceeds the %zu uploaded bases", n, ctx->nbases);
+  if (!out) bad_arg("null output pointer");
+  memset(ctx->last_ms, 0, sizeof ctx->last_ms);
+  memset(ctx->last_info, 0, sizeof ctx->last_info);
+  if (!st) st = ctx->own_stream;
+  if (ctx->curve == MI355_BLS12_377_G1)
+    run_device_t<Bls12_377_Fq>(ctx, (uint8_t*)out, (const uint32_t*)d_scalars, n, batches, st);
+  else
+    run_device_t<Bls12_381_Fq>(ctx, (uint8_t*)out, (const uint32_t*)d_scalars, n, batches, st);
+}
+
+template <class F>
+void fold_t(uint8_t* out, const uint8_t* in, size_t count) {
+  Modulus<F> md;
+  Xyzz total;
+  xyzz_set_inf<F>(total);
+  for (size_t i = 0; i < count; i++) {
+    Xyzz p;
+    xyzz_from_projective_abi<F>(p, in + 144 * i, md);
+    xyzz_add<F>(total, p, md);
+  }
+  xyzz_to_projective_abi<F>(out, total, md);
+}
+
+}  // namespace
+
+extern "C" {
+
+RustError mi355_msm_create(mi355_msm_ctx** out, int curve, int device) {
+  return guarded([&] {
+    if (!out) bad_arg("null context out-pointer");
+    *out = nullptr;
+    if (curve != MI355_BLS12_377_G1 && curve != MI355_BLS12_381_G1) bad_arg("unknown curve id %d", curve);
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count == 0)
+      throw HipFailure((int)(e != hipSuccess ? e : hipErrorNoDevice),
+                       "mi355_msm: no HIP device visible (this library has no CPU fallback)");
+    if (device < 0) HIP_OK(hipGetDevice(&device));
+    if (device >= count) bad_arg("device %d out of range (%d visible)", device, count);
+    HIP_OK(hipSetDevice(device));
+    mi355_msm_ctx* ctx = new mi355_msm_ctx();
+    ctx->curve = curve;
+    ctx->device = device;
+    HIP_OK(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
+    for (auto& ev : ctx->ev) HIP_OK(hipEventCreate(&ev));
+    *out = ctx;
+  });
+}
+
+RustError mi355_msm_destroy(mi355_msm_ctx* ctx) {
+  return guarded([&] {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->own_stream);
+    DevBuf* bufs[] = {&ctx->bases, &ctx->inf, &ctx->scalars, &ctx->keys[0], &ctx->keys[1], &ctx->vals[0], &ctx->vals[1],
+                      &ctx->sort_tmp, &ctx->buckets, &ctx->slots[0], &ctx->slots[1], &ctx->slot_keys[0], &ctx->slot_keys[1],
+                      &ctx->red_a[0], &ctx->red_a[1], &ctx->red_x[0], &ctx->red_x[1]};
+    for (DevBuf* b : bufs) b->release();
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    for (auto& ev : ctx->ev)
+      if (ev) (void)hipEventDestroy(ev);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+  });
+}
+
+RustError mi355_msm_set_bases(mi355_msm_ctx* ctx, const void* affine, size_t npoints, size_t stride) {
+  return guarded([&] {
+    if (!ctx) bad_arg("null context");
+    if (npoints && !affine) bad_arg("null bases pointer");
+    ensure_device(ctx);
+    DevBuf raw;
+    try {
+      if (npoints) {
+        raw.reserve(npoints * stride);
+        HIP_OK(hipMemcpy(raw.p, affine, npoints * stride, hipMemcpyHostToDevice));
+      }
+      set_bases_device(ctx, raw.p, npoints, stride);
+    } catch (...) {
+      raw.release();
+      throw;
+    }
+    raw.release();
+  });
+}
+
+RustError mi355_msm_set_bases_device(mi355_msm_ctx* ctx, const void* d_affine, size_t npoints, size_t stride) {
+  return guarded([&] {
+    if (!ctx) bad_arg("null context");
+    if (npoints && !d_affine) bad_arg("null bases pointer");
+    // the producer (e.g. torch) may have written the buffer on another stream: make it visible first
+    ensure_device(ctx);
+    HIP_OK(hipDeviceSynchronize());
+    set_bases_device(ctx, d_affine, npoints, stride);
+  });
+}
+
+RustError mi355_msm_run(mi355_msm_ctx* ctx, void* out, const void* scalars, size_t npoints, size_t batches) {
+  return guarded([&] {
+    if (!ctx) bad_arg("null context");
+    if (npoints * batches && !scalars) bad_arg("null scalars pointer");
+    ensure_device(ctx);
+    size_t bytes = npoints * batches * 32;
+    ctx->scalars.reserve(bytes ? bytes : 32);
+    if (bytes) HIP_OK(hipMemcpyAsync(ctx->scalars.p, scalars, bytes, hipMemcpyHostToDevice, ctx->own_stream));
+    run_device(ctx, out, ctx->scalars.p, npoints, batches, ctx->own_stream);
+  });
+}
+
+RustError mi355_msm_run_device(mi355_msm_ctx* ctx, void* out, const void* d_scalars, size_t npoints, size_t batches,
+                               void* stream) {
+  return guarded([&] {
+    if (!ctx) bad_arg("null context");
+    if (npoints * batches && !d_scalars) bad_arg("null scalars pointer");
+    run_device(ctx, out, d_scalars, npoints, batches, (hipStream_t)stream);
+  });
+}
+
+RustError mi355_msm_set_option(mi355_msm_ctx* ctx, const char* key, long value) {
+  return guarded([&] {
+    if (!ctx || !key) bad_arg("null argument");
+    std::string k(key);
+    if (k == "window_bits") {
+      if (value != 0 && (value < 2 || value > 24)) bad_arg("window_bits %ld out of range [2, 24]", value);
+      ctx->opt_window_bits = value;
+    } else if (k == "lane_entries") {
+      if (value < 0 || value > (1 << 20)) bad_arg("lane_entries %ld out of range", value);
+      ctx->opt_lane_entries = value;
+    } else if (k == "max_chunk") {
+      if (value < 0 || value > (1L << 27)) bad_arg("max_chunk %ld out of range [1, 2^27]", value);
+      ctx->opt_max_chunk = value;
+    } else if (k == "seg_entries") {
+      if (value != 0 && (value < 2 || value > 4096)) bad_arg("seg_entries %ld out of range", value);
+      ctx->opt_seg_entries = value;
+    } else {
+      bad_arg("unknown option '%s'", key);
+    }
+  });
+}
+
+RustError mi355_msm_last_timings(mi355_msm_ctx* ctx, float* ms, uint64_t* info) {
+  return guarded([&] {
+    if (!ctx) bad_arg("null context");
+    if (ms) memcpy(ms, ctx->last_ms, sizeof ctx->last_ms);
+    if (info) memcpy(info, ctx->last_info, 6 * sizeof(uint64_t));
+  });
+}
+
+RustError mi355_msm(int curve, void* out, const void* affine, size_t npoints, const void* scalars, size_t ffi_affine_sz) {
+  mi355_msm_ctx* ctx = nullptr;
+  RustError e = mi355_msm_create(&ctx, curve, -1);
+  if (e.code) return e;
+  e = mi355_msm_set_bases(ctx, affine, npoints, ffi_affine_sz);
+  if (!e.code) e = mi355_msm_run(ctx, out, scalars, npoints, 1);
+  RustError d = mi355_msm_destroy(ctx);
+  if (d.code) free(d.message);
+  return e;
+}
+
+RustError mi355_msm_fold(int curve, void* out, const void* projective, size_t count) {
+  return guarded([&] {
+    if (!out || (count && !projective)) bad_arg("null pointer");
+    if (curve == MI355_BLS12_377_G1)
+      fold_t<Bls12_377_Fq>((uint8_t*)out, (const uint8_t*)projective, count);
+    else if (curve == MI355_BLS12_381_G1)
+      fold_t<Bls12_381_Fq>((uint8_t*)out, (const uint8_t*)projective, count);
+    else
+      bad_arg("unknown curve id %d", curve);
+  });
+}
+
+const char* mi355_msm_version(void) { return "mi355-msm 0.1 (gfx950)"; }
+
+}  // extern "C"

@@ -1,0 +1,276 @@
+"""ctypes binding of libmi355msm.so plus the host-side mirror of the reference operator API.
+
+Mirrors (names, argument meaning, error behaviour) the Rust layer every prize1a entry exposes:
+
+  * ``multi_scalar_mult_init(points) -> MultiScalarMultContext`` and
+    ``multi_scalar_mult(ctx, points, scalars) -> Vec<G::Projective>`` with
+    ``batch_size = scalars.len() / points.len()``
+    (P1A 6block/src/lib.rs:54-109, yrrid/src/lib.rs:38-90; the Rust side panics on a non-zero
+    error code -- here that is ``MsmError``);
+  * ``VariableBaseMSM::msm(bases, scalars)`` truncating to the shorter slice and ``msm_checked``
+    (ARK ec/src/msm/variable_base/mod.rs:44-65).
+
+Inputs are the byte images the reference passes across its FFI: arkworks
+``G1Affine`` arrays (104-B stride), ``BigInteger256`` arrays (32 B), results are 144-B normalised
+``G1Projective`` images.  They may be ``bytes``/``bytearray``/NumPy uint8 arrays (host) or torch uint8
+tensors (host or device; device tensors are used in place through their ``data_ptr``).
+
+There is no CPU fallback here: if the HIP library is missing or no GPU is visible, calls raise.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import List, Optional, Sequence
+
+CURVE_IDS = {"bls12_377_g1": 0, "bls12_381_g1": 1}
+AFFINE_STRIDE = 104
+SCALAR_BYTES = 32
+PROJECTIVE_BYTES = 144
+T_NAMES = ("digits", "sort", "accumulate", "segreduce", "bucket_reduce", "host_fold", "total")
+
+_LIB = None
+
+
+class MsmError(RuntimeError):
+    """Non-zero RustError from the C ABI (the Rust harness panics here)."""
+
+    def __init__(self, code: int, message: str):
+        super().__init__(f"mi355_msm error {code}: {message}")
+        self.code = code
+        self.message = message
+
+
+class _RustError(ctypes.Structure):
+    _fields_ = [("code", ctypes.c_int), ("message", ctypes.c_void_p)]
+
+
+def library_path() -> str:
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmi355msm.so")
+
+
+def load_library() -> ctypes.CDLL:
+    """Load the HIP shared library built by ``__graft_entry__.build()``; fail loudly when absent."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"{path} is missing: build the gfx950 extension first (python -c 'import __graft_entry__ as g; g.build()'). "
+            "There is no CPU fallback for the MSM path.")
+    # torch bundles its own libamdhip64.so.7; whichever HIP runtime is mapped first serves the whole process.
+    # Import torch first so that tensors handed to this library and the library itself share ONE runtime.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    lib = ctypes.CDLL(path)
+    vp, sz, ci = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
+    sigs = {
+        "mi355_msm_create": [ctypes.POINTER(vp), ci, ci],
+        "mi355_msm_destroy": [vp],
+        "mi355_msm_set_bases": [vp, vp, sz, sz],
+        "mi355_msm_set_bases_device": [vp, vp, sz, sz],
+        "mi355_msm_run": [vp, vp, vp, sz, sz],
+        "mi355_msm_run_device": [vp, vp, vp, sz, sz, vp],
+        "mi355_msm_set_option": [vp, ctypes.c_char_p, ctypes.c_long],
+        "mi355_msm_last_timings": [vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_uint64)],
+        "mi355_msm": [ci, vp, vp, sz, vp, sz],
+        "mi355_msm_fold": [ci, vp, vp, sz],
+    }
+    for name, args in sigs.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = _RustError
+    lib.mi355_msm_version.restype = ctypes.c_char_p
+    _LIB = lib
+    return lib
+
+
+_libc = ctypes.CDLL(None)
+_libc.free.argtypes = [ctypes.c_void_p]
+
+
+def _check(err: _RustError) -> None:
+    if err.code != 0:
+        msg = ctypes.string_at(err.message).decode("utf-8", "replace") if err.message else "(no message)"
+        if err.message:
+            _libc.free(err.message)
+        raise MsmError(err.code, msg)
+
+
+def _curve_id(curve) -> int:
+    if isinstance(curve, int):
+        return curve
+    try:
+        return CURVE_IDS[curve]
+    except KeyError:
+        raise ValueError(f"unknown curve {curve!r}; known: {sorted(CURVE_IDS)}") from None
+
+
+class _Buf:
+    """Uniform view of bytes / numpy / torch inputs: pointer, byte length, device flag, keep-alive."""
+
+    def __init__(self, obj):
+        self.keep = obj
+        self.is_device = False
+        self.stream = None
+        if hasattr(obj, "data_ptr") and hasattr(obj, "is_cuda"):  # torch tensor
+            import torch
+
+            t = obj
+            if t.dtype != torch.uint8:
+                raise TypeError("tensor inputs must be torch.uint8 byte images")
+            if not t.is_contiguous():
+                t = t.contiguous()
+            self.keep = t
+            self.ptr = t.data_ptr()
+            self.nbytes = t.numel()
+            self.is_device = bool(t.is_cuda)
+            if self.is_device:
+                self.device_index = t.device.index if t.device.index is not None else torch.cuda.current_device()
+                self.stream = torch.cuda.current_stream(t.device).cuda_stream
+        elif hasattr(obj, "__array_interface__"):  # numpy
+            import numpy as np
+
+            a = np.ascontiguousarray(obj)
+            if a.dtype != np.uint8:
+                a = a.view(np.uint8)
+            self.keep = a
+            self.ptr = a.ctypes.data
+            self.nbytes = a.nbytes
+        else:
+            b = obj if isinstance(obj, (bytes, bytearray)) else bytes(obj)
+            self.keep = (ctypes.c_char * len(b)).from_buffer_copy(b) if len(b) else ctypes.create_string_buffer(1)
+            self.ptr = ctypes.addressof(self.keep)
+            self.nbytes = len(b)
+
+
+class MultiScalarMultContext:
+    """``#[repr(C)] struct MultiScalarMultContext { context: *mut c_void }`` (P1A 6block/src/lib.rs:18-21)."""
+
+    def __init__(self, curve="bls12_377_g1", device: Optional[int] = None):
+        self.curve = _curve_id(curve)
+        self._lib = load_library()
+        self.context = ctypes.c_void_p()
+        _check(self._lib.mi355_msm_create(ctypes.byref(self.context), self.curve, -1 if device is None else device))
+        self.npoints = 0
+
+    def set_bases(self, points, stride: int = AFFINE_STRIDE) -> None:
+        b = _Buf(points)
+        if b.nbytes % stride:
+            raise ValueError(f"points image of {b.nbytes} bytes is not a multiple of the {stride}-byte affine stride")
+        n = b.nbytes // stride
+        fn = self._lib.mi355_msm_set_bases_device if b.is_device else self._lib.mi355_msm_set_bases
+        _check(fn(self.context, b.ptr, n, stride))
+        self.npoints = n
+
+    def run(self, scalars, npoints: Optional[int] = None) -> List[bytes]:
+        b = _Buf(scalars)
+        n = self.npoints if npoints is None else npoints
+        if b.nbytes % SCALAR_BYTES:
+            raise ValueError("scalars image is not a multiple of 32 bytes")
+        count = b.nbytes // SCALAR_BYTES
+        if n == 0:
+            batches = 1 if count == 0 else None
+        else:
+            batches = count // n if count % n == 0 else None
+        if batches is None:
+            raise ValueError(f"{count} scalars is not a whole number of batches of {n} points")
+        out = ctypes.create_string_buffer(PROJECTIVE_BYTES * max(batches, 1))
+        if b.is_device:
+            _check(self._lib.mi355_msm_run_device(self.context, out, b.ptr, n, batches, b.stream))
+        else:
+            _check(self._lib.mi355_msm_run(self.context, out, b.ptr, n, batches))
+        raw = out.raw
+        return [raw[i * PROJECTIVE_BYTES:(i + 1) * PROJECTIVE_BYTES] for i in range(batches)]
+
+    def set_option(self, key: str, value: int) -> None:
+        _check(self._lib.mi355_msm_set_option(self.context, key.encode(), int(value)))
+
+    def last_timings(self) -> dict:
+        ms = (ctypes.c_float * 8)()
+        info = (ctypes.c_uint64 * 6)()
+        _check(self._lib.mi355_msm_last_timings(self.context, ms, info))
+        d = {name: float(ms[i]) for i, name in enumerate(T_NAMES)}
+        d.update(window_bits=int(info[0]), windows=int(info[1]), entries=int(info[2]), lane_entries=int(info[3]),
+                 launches=int(info[4]), lanes=int(info[5]))
+        return d
+
+    def close(self) -> None:
+        if self.context:
+            _check(self._lib.mi355_msm_destroy(self.context))
+            self.context = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def multi_scalar_mult_init(points, curve="bls12_377_g1", device: Optional[int] = None) -> MultiScalarMultContext:
+    """Upload (and convert) the fixed base vector once; untimed in the reference bench (benches/msm.rs:21)."""
+    ctx = MultiScalarMultContext(curve, device)
+    ctx.set_bases(points)
+    return ctx
+
+
+def multi_scalar_mult(ctx: MultiScalarMultContext, points, scalars) -> List[bytes]:
+    """One 144-byte projective image per batch; ``points`` is only used for its length, as in the reference
+    (``npoints = points.len()``, P1A 6block/src/lib.rs:92-101)."""
+    npoints = ctx.npoints if points is None else _Buf(points).nbytes // AFFINE_STRIDE
+    if npoints != ctx.npoints:
+        raise MsmError(-1, f"context was initialised with {ctx.npoints} points, called with {npoints}")
+    return ctx.run(scalars, npoints)
+
+
+def msm(bases, scalars, curve="bls12_377_g1") -> bytes:
+    """Stateless ``msm(bases, scalars, n)``; chops to the shorter input like VariableBaseMSM::msm."""
+    nb = _Buf(bases).nbytes // AFFINE_STRIDE
+    ns = _Buf(scalars).nbytes // SCALAR_BYTES
+    n = min(nb, ns)
+    ctx = MultiScalarMultContext(curve)
+    try:
+        pb, sb = _Buf(bases), _Buf(scalars)
+        if pb.is_device or sb.is_device:
+            ctx.set_bases(bases[: n * AFFINE_STRIDE])
+            return ctx.run(scalars[: n * SCALAR_BYTES], n)[0]
+        out = ctypes.create_string_buffer(PROJECTIVE_BYTES)
+        _check(ctx._lib.mi355_msm(ctx.curve, out, pb.ptr, n, sb.ptr, AFFINE_STRIDE))
+        return out.raw
+    finally:
+        ctx.close()
+
+
+class VariableBaseMSM:
+    """Shape of the arkworks trait (ARK ec/src/msm/variable_base/mod.rs:15-65) for one curve."""
+
+    def __init__(self, curve="bls12_377_g1"):
+        self.curve = curve
+
+    def msm(self, bases, scalars) -> bytes:
+        return msm(bases, scalars, self.curve)
+
+    def msm_checked(self, bases, scalars):
+        """``Ok(point)`` as bytes, or ``Err(min_len)`` as an int when lengths differ."""
+        nb = _Buf(bases).nbytes // AFFINE_STRIDE
+        ns = _Buf(scalars).nbytes // SCALAR_BYTES
+        if nb != ns:
+            return min(nb, ns)
+        return self.msm(bases, scalars)
+
+    msm_bigint = msm
+
+
+def fold_partials(partials: Sequence[bytes], curve="bls12_377_g1") -> bytes:
+    """Sum per-GPU partial results (144-B projective images) into one normalised image."""
+    lib = load_library()
+    blob = b"".join(bytes(p) for p in partials)
+    if len(blob) % PROJECTIVE_BYTES:
+        raise ValueError("partials must be 144-byte projective images")
+    out = ctypes.create_string_buffer(PROJECTIVE_BYTES)
+    buf = ctypes.create_string_buffer(blob, len(blob) if blob else 1)
+    _check(lib.mi355_msm_fold(_curve_id(curve), out, buf, len(blob) // PROJECTIVE_BYTES))
+    return out.raw

@@ -1,0 +1,112 @@
+/* mi355_msm.h -- C ABI of the MI355X (gfx950) multi-scalar-multiplication engine.
+ *
+ * This is the drop-in boundary for the ZPrize-2022 prize1-msm hot path: plain pointers and sizes,
+ * no C++ or torch types.  Every entry point names the reference interface it replaces
+ * (paths relative to /root/reference, abbreviations as in SURVEY.md):
+ *
+ *   SPK  = open-division/prize1-msm/prize1a-msm-gpu/6block/sppark
+ *   P1A  = open-division/prize1-msm/prize1a-msm-gpu
+ *   CMB  = P1A/combined-top-solutions/combined-msm
+ *   ARK  = open-division/prize4-msm-wasm/snarkify/zprize-prize4-15ac8c55-arkworks-algebra
+ *
+ * Data layouts (identical to what the reference FFI passes):
+ *   bases    arkworks `Affine` images: x, y as 6 x u64 little-endian Montgomery (R = 2^384) limbs,
+ *            then a 1-byte infinity flag; element stride is passed explicitly (104 B for G1).
+ *            The flag byte is authoritative for infinity, not the coordinates.
+ *   scalars  32 B each, 4 x u64 little-endian, plain integers (`BigInteger256`).
+ *   results  arkworks `Projective` images (Jacobian X, Y, Z; 3 x 48 B Montgomery), written NORMALISED:
+ *            (x, y, 1), or (1, 1, 0) for the point at infinity -- so equal points are equal bytes.
+ *
+ * Errors: `RustError { int code; char *message; }` returned by value, exactly sppark's convention
+ * (SPK util/rusterror.h:15-27): code 0 = success, otherwise a hipError_t value (or -1 for argument
+ * errors) and a malloc'd message the caller frees (Rust side: SPK rust/src/lib.rs:17-25).  A message is
+ * ALWAYS supplied on failure, because ROCm has no cudaGetErrorString for the Rust macro to fall back on.
+ * No C++ exception crosses this boundary.
+ *
+ * There is no CPU fallback: every compute entry point needs a visible gfx950 device and fails with
+ * hipErrorNoDevice otherwise.
+ */
+#ifndef MI355_MSM_H
+#define MI355_MSM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct {
+  int code;
+  char* message;
+} RustError;
+
+typedef struct mi355_msm_ctx mi355_msm_ctx;
+
+enum {
+  MI355_BLS12_377_G1 = 0, /* fq: ARKC bls12_377/src/fields/fq.rs:4, curve b = 1 */
+  MI355_BLS12_381_G1 = 1  /* fq: ARKC bls12_381/src/fields/fq.rs:4, curve b = 4 */
+};
+
+/* Stage indices of mi355_msm_last_timings(). */
+enum {
+  MI355_T_DIGITS = 0,
+  MI355_T_SORT = 1,
+  MI355_T_ACCUMULATE = 2, /* the dominant kernel (bucket accumulation) */
+  MI355_T_SEGREDUCE = 3,
+  MI355_T_BUCKET_REDUCE = 4,
+  MI355_T_HOST_FOLD = 5,
+  MI355_T_TOTAL = 6,
+  MI355_T_COUNT = 8
+};
+
+/* ---- canonical context API ---------------------------------------------------------------------
+ * Replaces the context half of the harness FFI: mult_pippenger_init / mult_pippenger_inf
+ * (P1A 6block/cuda/pippenger_inf.cu:50-53, 87-92) and MSMAllocContext / MSMPreprocessPoints / MSMRun /
+ * MSMFreeContext (CMB MSM.h:72-75).  Bases are uploaded and converted once; each run streams scalars. */
+
+/* device < 0 selects the current HIP device. */
+RustError mi355_msm_create(mi355_msm_ctx** out, int curve, int device);
+RustError mi355_msm_destroy(mi355_msm_ctx* ctx);
+
+/* Bases in HOST memory (arkworks Affine images, `stride` bytes apart).  Copies; caller keeps ownership. */
+RustError mi355_msm_set_bases(mi355_msm_ctx* ctx, const void* affine, size_t npoints, size_t stride);
+/* Same, bases already resident in DEVICE memory (e.g. a torch uint8 tensor's data_ptr). */
+RustError mi355_msm_set_bases_device(mi355_msm_ctx* ctx, const void* d_affine, size_t npoints, size_t stride);
+
+/* `batches` MSMs over the SAME bases: scalars holds batches * npoints entries, out receives `batches`
+ * projective images (P1A 6block/src/lib.rs:85-109: batch_size = scalars.len() / points.len()).
+ * npoints may be smaller than the number of uploaded bases (prefix). */
+RustError mi355_msm_run(mi355_msm_ctx* ctx, void* out_projective, const void* scalars, size_t npoints, size_t batches);
+/* Scalars already in DEVICE memory; `stream` is a hipStream_t (NULL = the context's own stream) on which the
+ * scalars are ready and on which all work is enqueued.  `out_projective` is HOST memory; the call returns
+ * after the result is written (one stream synchronisation per batch chunk). */
+RustError mi355_msm_run_device(mi355_msm_ctx* ctx, void* out_projective, const void* d_scalars, size_t npoints,
+                               size_t batches, void* stream);
+
+/* Tuning knobs ("window_bits", "lane_entries", "max_chunk", "seg_entries"); 0 restores the automatic choice.
+ * Mirrors Matter Labs' runtime msm_configuration (P1A matter-labs/.../bellman-cuda.h:49-71). */
+RustError mi355_msm_set_option(mi355_msm_ctx* ctx, const char* key, long value);
+/* Per-stage device time (ms, HIP events on the launch stream) of the most recent run, summed over its chunks
+ * and batches; ms must hold MI355_T_COUNT floats.  info: [0]=window bits, [1]=windows, [2]=sorted entries of the
+ * last chunk, [3]=entries per lane, [4]=accumulate launches, [5]=lanes of the last launch. */
+RustError mi355_msm_last_timings(mi355_msm_ctx* ctx, float* ms, uint64_t* info);
+
+/* ---- stateless calls ---------------------------------------------------------------------------
+ * sppark's mult_pippenger_inf(out, points, npoints, scalars, ffi_affine_sz)
+ * (SPK poc/blst-cuda/cuda/pippenger_inf.cu:28-35) with the curve made explicit; BASELINE.json's
+ * `msm(bases, scalars, n)` is mi355_msm(curve, out, bases, n, scalars, 104). */
+RustError mi355_msm(int curve, void* out_projective, const void* affine, size_t npoints, const void* scalars,
+                    size_t ffi_affine_sz);
+
+/* Sum `count` projective images (any Z) into one normalised image: the multi-GPU combine step
+ * ("final 8-point curve add").  Pure host arithmetic on <= a few dozen points; no device needed. */
+RustError mi355_msm_fold(int curve, void* out_projective, const void* projective, size_t count);
+
+/* Library/ABI version and the gfx target the kernels were built for ("gfx950"). */
+const char* mi355_msm_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355_MSM_H */
