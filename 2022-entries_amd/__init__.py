@@ -9,9 +9,11 @@ from .msm import (  # noqa: F401
     MultiScalarMultContext,
     VariableBaseMSM,
     fold_partials,
+    generate_points,
     library_path,
     load_library,
     multi_scalar_mult,
     multi_scalar_mult_init,
     msm,
 )
+from .dist import all_gather_partials, shard_bounds, sharded_msm  # noqa: F401,E402

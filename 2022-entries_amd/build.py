@@ -1,0 +1,68 @@
+"""Build the native pieces in-tree (the .so files are git-ignored but travel with the gpurun snapshot).
+
+  libmi355msm.so       hipcc --offload-arch=gfx950: kernels + engine + C ABI (the product)
+  libmsm_hosttest.so   g++: the same fp28/curve templates for the host with the limb-bound checker (tests only)
+  oracle/liboracle.so  gcc: CPU restatement of the arkworks algorithm (tests / smoke / bench cpu_baseline only)
+  oracle/_ref/*        reference-derived cross-checks, only when /root/reference exists
+"""
+from __future__ import annotations
+
+import glob
+import os
+import shutil
+import subprocess
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+
+
+def _newer(target: str, deps) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _run(cmd, **kw):
+    print("+", " ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True, **kw)
+
+
+def hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: the MSM engine is HIP-only (no CPU fallback)")
+
+
+def build_engine(force: bool = False) -> str:
+    out = os.path.join(PKG, "libmi355msm.so")
+    deps = glob.glob(os.path.join(CSRC, "*")) + glob.glob(os.path.join(ROOT, "include", "*.h"))
+    if force or _newer(out, deps):
+        _run([hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
+              "-o", out, os.path.join(CSRC, "msm_engine.hip")])
+    return out
+
+
+def build_hosttest(force: bool = False) -> str:
+    out = os.path.join(PKG, "libmsm_hosttest.so")
+    deps = glob.glob(os.path.join(CSRC, "*"))
+    if force or _newer(out, deps):
+        _run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", out, os.path.join(CSRC, "host_test_api.cpp")])
+    return out
+
+
+def build_oracle() -> str:
+    _run(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
+    return os.path.join(ROOT, "oracle", "liboracle.so")
+
+
+def build_all(force: bool = False) -> None:
+    build_engine(force)
+    build_hosttest(force)
+    build_oracle()
+
+
+if __name__ == "__main__":
+    build_all()

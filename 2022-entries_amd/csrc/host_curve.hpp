@@ -113,4 +113,81 @@ inline void fold_windows(Xyzz& acc, const Xyzz* sums, int windows, int c, const 
   }
 }
 
+// Synthetic input generator in the shape of the reference harness (P1A yrrid/src/util.rs:15-28,
+// 6block/src/util.rs:15-29): `distinct` subgroup points P_j = (h0 + j*h1) * G, batch-normalised to affine
+// (one inversion, Montgomery's trick), written as arkworks Affine images and replicated by doubling the
+// vector up to `npoints`.
+inline uint64_t splitmix64(uint64_t& s) {
+  uint64_t z = (s += 0x9e3779b97f4a7c15ull);
+  z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+  z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+  return z ^ (z >> 31);
+}
+
+template <class F>
+inline void xyzz_mul_u64x4(Xyzz& r, const Affine& g, const uint64_t k[4], const Modulus<F>& md) {
+  xyzz_set_inf<F>(r);
+  for (int bit = 255; bit >= 0; bit--) {
+    if (!xyzz_is_inf<F>(r)) xyzz_dbl<F>(r, md);
+    if ((k[bit >> 6] >> (bit & 63)) & 1) xyzz_madd<F>(r, g, false, false, md);
+  }
+}
+
+template <class F>
+inline void generate_points(uint64_t seed, size_t distinct, size_t npoints, uint8_t* out, size_t stride) {
+  Modulus<F> md;
+  if (distinct > npoints) distinct = npoints;
+  if (distinct == 0) return;
+  Affine g;
+  fe_set(g.x, F::G1X);
+  fe_set(g.y, F::G1Y);
+  uint64_t st = seed, h0[4], h1[4];
+  for (int i = 0; i < 4; i++) h0[i] = splitmix64(st);
+  for (int i = 0; i < 4; i++) h1[i] = splitmix64(st);
+  h0[3] &= 0x03ffffffffffffffull;  // 250-bit multipliers: below both group orders
+  h1[3] &= 0x03ffffffffffffffull;
+  h1[0] |= 1;
+  Xyzz acc, step;
+  xyzz_mul_u64x4<F>(acc, g, h0, md);
+  xyzz_mul_u64x4<F>(step, g, h1, md);
+  Xyzz* pts = new Xyzz[distinct];
+  Fe* prefix = new Fe[distinct];
+  Fe run;
+  fe_set(run, F::ONE);
+  for (size_t j = 0; j < distinct; j++) {
+    if (xyzz_is_inf<F>(acc)) xyzz_add<F>(acc, step, md);  // (measure-zero) skip the identity
+    pts[j] = acc;
+    prefix[j] = run;                       // product of zz*zzz of all earlier points
+    Fe t;
+    fe_mul<F>(t, acc.zz, acc.zzz, md);
+    fe_mul<F>(run, run, t, md);
+    xyzz_add<F>(acc, step, md);
+  }
+  Fe inv;
+  fe_inv<F>(inv, run, md);
+  for (size_t j = distinct; j-- > 0;) {
+    Fe t, ti, zzi, zzzi, x, y;
+    fe_mul<F>(ti, inv, prefix[j], md);     // (zz_j*zzz_j)^-1
+    fe_mul<F>(t, pts[j].zz, pts[j].zzz, md);
+    fe_mul<F>(inv, inv, t, md);
+    fe_mul<F>(zzi, ti, pts[j].zzz, md);
+    fe_mul<F>(zzzi, ti, pts[j].zz, md);
+    fe_mul<F>(x, pts[j].x, zzi, md);
+    fe_mul<F>(y, pts[j].y, zzzi, md);
+    uint32_t w[24];
+    fe_to_abi<F>(w, x, md);
+    fe_to_abi<F>(w + 12, y, md);
+    uint8_t* o = out + j * stride;
+    memset(o, 0, stride);
+    memcpy(o, w, 96);
+  }
+  delete[] pts;
+  delete[] prefix;
+  for (size_t have = distinct; have < npoints;) {
+    size_t cp = have < npoints - have ? have : npoints - have;
+    memcpy(out + have * stride, out, cp * stride);
+    have += cp;
+  }
+}
+
 }  // namespace msm

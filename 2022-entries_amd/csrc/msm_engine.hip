@@ -502,6 +502,19 @@ RustError mi355_msm_fold(int curve, void* out, const void* projective, size_t co
   });
 }
 
+RustError mi355_msm_generate_points(int curve, uint64_t seed, size_t distinct, size_t npoints, void* out, size_t stride) {
+  return guarded([&] {
+    if (npoints && !out) bad_arg("null output pointer");
+    if (stride < 97) bad_arg("affine stride %zu too small", stride);
+    if (curve == MI355_BLS12_377_G1)
+      generate_points<Bls12_377_Fq>(seed, distinct, npoints, (uint8_t*)out, stride);
+    else if (curve == MI355_BLS12_381_G1)
+      generate_points<Bls12_381_Fq>(seed, distinct, npoints, (uint8_t*)out, stride);
+    else
+      bad_arg("unknown curve id %d", curve);
+  });
+}
+
 const char* mi355_msm_version(void) { return "mi355-msm 0.1 (gfx950)"; }
 
 }  // extern "C"

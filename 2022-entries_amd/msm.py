@@ -78,6 +78,7 @@ def load_library() -> ctypes.CDLL:
         "mi355_msm_last_timings": [vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_uint64)],
         "mi355_msm": [ci, vp, vp, sz, vp, sz],
         "mi355_msm_fold": [ci, vp, vp, sz],
+        "mi355_msm_generate_points": [ci, ctypes.c_uint64, sz, sz, vp, sz],
     }
     for name, args in sigs.items():
         fn = getattr(lib, name)
@@ -274,3 +275,14 @@ def fold_partials(partials: Sequence[bytes], curve="bls12_377_g1") -> bytes:
     buf = ctypes.create_string_buffer(blob, len(blob) if blob else 1)
     _check(lib.mi355_msm_fold(_curve_id(curve), out, buf, len(blob) // PROJECTIVE_BYTES))
     return out.raw
+
+
+def generate_points(npoints: int, distinct: int = 1 << 15, seed: int = 0x5A5052495A45, curve="bls12_377_g1"):
+    """Synthetic bases in the reference generator's shape (P1A yrrid/src/util.rs:15-28): ``distinct`` subgroup points
+    replicated by doubling up to ``npoints``; returns a NumPy uint8 array of shape (npoints, 104)."""
+    import numpy as np
+
+    lib = load_library()
+    out = np.zeros((npoints, AFFINE_STRIDE), dtype=np.uint8)
+    _check(lib.mi355_msm_generate_points(_curve_id(curve), seed, distinct, npoints, out.ctypes.data, AFFINE_STRIDE))
+    return out

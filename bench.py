@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""bench.py -- BLS12-377 G1 MSM throughput on MI355X (BASELINE.json metric), one process per GPU.
+
+  python bench.py --gpus 1 --steps 5 --warmup 1
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" is one MSM of 2^npow point-scalar pairs per GPU (default 2^26, BASELINE.json configs[1]) with the bases
+AND the scalars already resident in HBM: device scalars -> digits -> sort -> bucket accumulation -> bucket reduction ->
+window sums to the host -> Horner fold; with N > 1 ranks each rank owns a disjoint slice (weak scaling: 2^npow pairs
+per GPU), the N 144-byte partials are all-gathered with RCCL and folded on every rank.  Rank 0 prints ONE JSON line.
+
+`roofline` is for the dominant kernel (bucket accumulation, k_accumulate): algorithmic bytes = 128 B/pair
+(32 B scalar + 96 B affine base) x pairs per launch, over its HIP-event duration on the launch stream.
+`cpu_baseline` times oracle/liboracle.so -- the C restatement of arkworks' VariableBaseMSM, one thread per window like
+rayon -- on a bounded sample of the same workload, rank 0, N = 1 only.  It is a reported baseline, not the target.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+BYTES_PER_PAIR = 128.0          # 32 B scalar + 96 B affine base
+R377_TOP = 0x12ab655e9a2ca556   # top 64-bit limb of the BLS12-377 scalar modulus (ARKC bls12_377/src/fields/fr.rs:24)
+R381_TOP = 0x73eda753299d7d48
+
+
+def uniform_scalars(n, top_limb, device, seed):
+    """n integers uniform on [0, top_limb * 2^192), a subset of [0, r): 4 x u64 little-endian limbs as a uint8 tensor."""
+    import torch
+
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    limbs = torch.randint(-(1 << 63), (1 << 63) - 1, (n, 4), dtype=torch.int64, device=device, generator=g)
+    bits = top_limb.bit_length()
+    top = limbs[:, 3] & ((1 << bits) - 1)
+    for _ in range(64):
+        bad = top >= top_limb
+        nbad = int(bad.sum().item())
+        if nbad == 0:
+            break
+        top[bad] = torch.randint(0, 1 << bits, (nbad,), dtype=torch.int64, device=device, generator=g)
+    limbs[:, 3] = top
+    return limbs.view(torch.uint8).reshape(n, 32)
+
+
+def cpu_baseline(curve, cid, bases_np, scalars_np, sample, threads):
+    """Time the oracle (arkworks-algorithm restatement) on `sample` pairs; returns (pairs/s, result bytes, seconds)."""
+    lib = ctypes.CDLL(os.path.join(ROOT, "oracle", "liboracle.so"))
+    out = ctypes.create_string_buffer(144)
+    t0 = time.perf_counter()
+    rc = lib.oracle_msm(cid, bases_np.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(104),
+                        scalars_np.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(sample), out, threads)
+    dt = time.perf_counter() - t0
+    if rc != 0:
+        raise RuntimeError("oracle_msm failed")
+    return sample / dt, out.raw, dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--npow", type=int, default=26, help="log2 pairs per GPU (26 = ZPrize prize1-msm canonical size)")
+    ap.add_argument("--curve", default="bls12_377_g1", choices=["bls12_377_g1", "bls12_381_g1"])
+    ap.add_argument("--cpu-sample-pow", type=int, default=24, help="log2 pairs of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--window-bits", type=int, default=0)
+    ap.add_argument("--lane-entries", type=int, default=0)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import entries_amd as ea
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the MSM path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=device)
+
+    cid = ea.CURVE_IDS[args.curve]
+    n = 1 << args.npow
+    distinct = min(n, 1 << 15)
+    # synthetic inputs in the reference generator's shape: 2^15 distinct subgroup points replicated to n,
+    # uniform scalars below r; every rank has its own slice of the global problem (different scalars per rank)
+    base_tile = ea.generate_points(distinct, distinct=distinct, seed=0x5A5052495A45 + cid, curve=args.curve)
+    tile = torch.from_numpy(base_tile).to(device)
+    bases = tile.repeat(n // distinct, 1).contiguous()
+    scalars = uniform_scalars(n, R377_TOP if cid == 0 else R381_TOP, device, seed=1234 + rank)
+    ctx = ea.MultiScalarMultContext(args.curve, device=local_rank)
+    ctx.set_bases(bases)
+    del bases
+    if args.window_bits:
+        ctx.set_option("window_bits", args.window_bits)
+    if args.lane_entries:
+        ctx.set_option("lane_entries", args.lane_entries)
+
+    def step():
+        partial = ctx.run(scalars)[0]
+        if world > 1:
+            return ea.fold_partials(ea.all_gather_partials(partial, device=device), args.curve)
+        return partial
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    acc_ms, acc_launches, stage_ms = 0.0, 0, {}
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        result = step()
+        tm = ctx.last_timings()
+        acc_ms += tm["accumulate"]
+        acc_launches += tm["launches"]
+        for k in ("digits", "sort", "accumulate", "segreduce", "bucket_reduce", "total"):
+            stage_ms[k] = stage_ms.get(k, 0.0) + tm[k]
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    if rank == 0:
+        pairs_per_step = n * world
+        value = pairs_per_step * args.steps / elapsed
+        kern_s = (acc_ms / max(acc_launches, 1)) * 1e-3
+        pairs_per_launch = n * args.steps / max(acc_launches, 1)
+        achieved = BYTES_PER_PAIR * pairs_per_launch / kern_s / 1e9
+        out = {
+            "metric": "BLS12-377 G1 MSM point-scalar pairs/s" if cid == 0 else "BLS12-381 G1 MSM point-scalar pairs/s",
+            "value": value,
+            "unit": "pairs/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_2^26_pairs": elapsed / args.steps * 1e3 * (1 << 26) / n,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32 limbs (radix-2^28 Montgomery, 64-bit MAD accumulate)",
+            "data": "synthetic: 2^15 distinct subgroup points replicated (reference generator shape), uniform scalars < r",
+            "config": {"workload": f"{args.curve} MSM, 2^{args.npow} pairs per GPU, bases+scalars resident in HBM",
+                       "pairs_per_gpu": n, "window_bits": tm["window_bits"], "windows": tm["windows"],
+                       "lane_entries": tm["lane_entries"], "parallelism": f"{world} disjoint base/scalar slices + all-gather of {world}x144 B"},
+            "stage_ms_per_step": {k: v / args.steps for k, v in stage_ms.items()},
+            "roofline": {"bound": "hbm", "kernel": "k_accumulate", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "kernel_ms": kern_s * 1e3, "algorithmic_bytes_per_launch": BYTES_PER_PAIR * pairs_per_launch,
+                         "note": "integer-VALU-bound path (no MFMA); see DESIGN.md for the v_mad_u64_u32 issue-rate roofline"},
+        }
+        if world == 1 and args.cpu_sample_pow > 0:
+            sample = min(n, 1 << args.cpu_sample_pow)
+            cores = os.cpu_count() or 1
+            bases_np = np.ascontiguousarray(np.tile(base_tile, (max(1, sample // distinct), 1))[:sample])
+            scal_np = scalars[:sample].cpu().numpy()
+            c = 3 if sample < 32 else (((sample - 1).bit_length()) * 69 // 100 + 2)
+            windows = -(-(253 if cid == 0 else 255) // c)
+            threads = min(windows, cores)
+            v, cpu_res, dt = cpu_baseline(args.curve, cid, bases_np, scal_np, sample, threads)
+            # same sample on the GPU: a parity spot-check next to the number
+            gpu_res = ctx.run(scalars[:sample].contiguous(), npoints=sample)[0]
+            out["cpu_baseline"] = {"value": v, "unit": "pairs/s", "cores": threads, "kind": "port",
+                                   "sample": f"first 2^{sample.bit_length() - 1} pairs of the same workload, {dt:.1f} s, "
+                                             f"arkworks-algorithm restatement (c={c}, one thread per window), host has {cores} cores",
+                                   "gpu_matches_cpu_on_sample": gpu_res == cpu_res}
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -103,6 +103,12 @@ RustError mi355_msm(int curve, void* out_projective, const void* affine, size_t 
  * ("final 8-point curve add").  Pure host arithmetic on <= a few dozen points; no device needed. */
 RustError mi355_msm_fold(int curve, void* out_projective, const void* projective, size_t count);
 
+/* Synthetic bases in the shape of the reference harness generator (P1A yrrid/src/util.rs:15-28): `distinct`
+ * subgroup points (h0 + j*h1)*G derived from `seed`, written as arkworks Affine images `stride` bytes apart into
+ * HOST memory and replicated by doubling the vector up to `npoints`.  Host arithmetic; no device needed. */
+RustError mi355_msm_generate_points(int curve, uint64_t seed, size_t distinct, size_t npoints, void* out_affine,
+                                    size_t stride);
+
 /* Library/ABI version and the gfx target the kernels were built for ("gfx950"). */
 const char* mi355_msm_version(void);
 
