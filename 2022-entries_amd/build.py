@@ -53,6 +53,23 @@ def build_hosttest(force: bool = False) -> str:
     return out
 
 
+def build_shims(force: bool = False) -> list:
+    """Harness-named symbol sets (include/mi355_msm_shims.h): tiny C objects linked against libmi355msm.so."""
+    outs = []
+    shim_dir = os.path.join(CSRC, "shims")
+    variants = [("sppark_stateless.c", "sppark", ("377", "381")), ("zprize_harness.c", "zprize", ("377", "381")),
+                ("yrrid_context.c", "yrrid", ("377",))]
+    for src, name, curves in variants:
+        for cv in curves:
+            out = os.path.join(PKG, f"libmi355msm_{name}_{cv}.so")
+            deps = [os.path.join(shim_dir, src)] + glob.glob(os.path.join(ROOT, "include", "*.h"))
+            if force or _newer(out, deps):
+                _run(["gcc", "-O2", "-shared", "-fPIC", f"-DFEATURE_BLS12_{cv}", "-o", out, os.path.join(shim_dir, src),
+                      f"-L{PKG}", "-lmi355msm", "-Wl,-rpath,$ORIGIN"])
+            outs.append(out)
+    return outs
+
+
 def build_oracle() -> str:
     _run(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
     return os.path.join(ROOT, "oracle", "liboracle.so")
@@ -61,6 +78,7 @@ def build_oracle() -> str:
 def build_all(force: bool = False) -> None:
     build_engine(force)
     build_hosttest(force)
+    build_shims(force)
     build_oracle()
 
 

@@ -53,28 +53,29 @@ MSM_HD void xyzz_from_affine(Xyzz& r, const Affine& p, bool negate) {
 // U1 (=X1 for madd) and S1 (=Y1), produce X3, Y3 and return PPP for the ZZ/ZZZ updates.
 //   X3 = R^2 - PPP - 2Q,  Y3 = R (Q - X3) - S1 PPP,  Q = U1 PP.
 template <class F>
-MSM_HD void add_tail(Fe& x3, Fe& y3, Fe& ppp, const Fe& P, const Fe& R, const Fe& PP, const Fe& U1, const Fe& S1,
+MSM_HD void add_tail(Fe& x3, Fe& y3, Fe& ppp, const Fe& P, Fe& R, const Fe& PP, const Fe& U1, const Fe& S1,
                      const Modulus<F>& md) {
-  Fe q, r2, t, d, t1, t2;
+  Fe q, r2, t, d, nppp;
   fe_mul<F>(ppp, P, PP, md);   // M
   fe_mul<F>(q, U1, PP, md);    // M
+  fe_carry(R);                 // limbs < 2^28 + 16 (value unchanged): lets R share a reduction below
   fe_sqr<F>(r2, R, md);        // M
   fe_dbl(t, q);                // < 4p, limbs < 2^29
   fe_add(t, t, ppp);           // < 6p, limbs < 3*2^28
   fe_sub(x3, r2, t, F::BIAS8_30);  // (2p, 10p), limbs < 2^28 + 2^30 + 2^28
   fe_carry(x3);                // limbs < 2^28 + 16
   fe_sub(d, q, x3, F::BIAS16_29);  // (6p, 18p), limbs < 2^30
-  fe_mul<F>(t1, R, d, md);     // M
-  fe_mul<F>(t2, S1, ppp, md);  // M
-  fe_sub(y3, t1, t2, F::BIAS2_28);  // (0, 4p), limbs < 3*2^28
-  fe_carry(y3);
+  fe_carry(d);                 // limbs < 2^28 + 16
+  fe_neg(nppp, ppp, F::BIAS2_28);  // -PPP as (0, 2p], limbs < 2^29
+  // Y3 = R*D - S1*PPP = R*D + S1*(-PPP): one reduction for both products; the result is class M
+  fe_mul2<F>(y3, R, d, S1, nppp, md);
 }
 
 // acc = 2 * (x2, y2) from affine coordinates (mdbl-2008-s-1).  y2 may be a negated (lazy) value with
 // limbs < 2^29.  A 2-torsion point (y = 0) yields ZZ = 0, i.e. infinity, with no special case.
 template <class F>
 MSM_HD void xyzz_dbl_affine(Xyzz& acc, const Fe& x2, const Fe& y2, const Modulus<F>& md) {
-  Fe u, v, w, s, xx, m, mm, t, d, t1, t2;
+  Fe u, v, w, s, xx, m, mm, t, d, nw;
   fe_dbl(u, y2);               // limbs < 2^30, value <= 4p
   fe_sqr<F>(v, u, md);
   fe_mul<F>(w, u, v, md);
@@ -82,15 +83,15 @@ MSM_HD void xyzz_dbl_affine(Xyzz& acc, const Fe& x2, const Fe& y2, const Modulus
   fe_sqr<F>(xx, x2, md);
   fe_dbl(m, xx);
   fe_add(m, m, xx);            // 3*XX: < 6p, limbs < 3*2^28
+  fe_carry(m);                 // limbs < 2^28 + 16
   fe_sqr<F>(mm, m, md);
   fe_dbl(t, s);                // < 4p, limbs < 2^29
   fe_sub(acc.x, mm, t, F::BIAS4_29);  // (0, 6p)
   fe_carry(acc.x);
   fe_sub(d, s, acc.x, F::BIAS8_29);   // (2p, 10p), limbs < 2^30
-  fe_mul<F>(t1, m, d, md);
-  fe_mul<F>(t2, w, y2, md);
-  fe_sub(acc.y, t1, t2, F::BIAS2_28);
-  fe_carry(acc.y);
+  fe_carry(d);
+  fe_neg(nw, w, F::BIAS2_28);
+  fe_mul2<F>(acc.y, m, d, y2, nw, md);  // M*(S - X3) - W*Y2   (y2 limbs < 2^29 also when negated)
   acc.zz = v;
   acc.zzz = w;
 }
@@ -98,7 +99,7 @@ MSM_HD void xyzz_dbl_affine(Xyzz& acc, const Fe& x2, const Fe& y2, const Modulus
 // acc = 2 * acc (dbl-2008-s-1).
 template <class F>
 MSM_HD void xyzz_dbl(Xyzz& acc, const Modulus<F>& md) {
-  Fe u, v, w, s, xx, m, mm, t, d, t1, t2;
+  Fe u, v, w, s, xx, m, mm, t, d, nw, y1 = acc.y;
   fe_dbl(u, acc.y);            // limbs < 2^29 + 32, value < 32p
   fe_sqr<F>(v, u, md);
   fe_mul<F>(w, u, v, md);
@@ -106,15 +107,15 @@ MSM_HD void xyzz_dbl(Xyzz& acc, const Modulus<F>& md) {
   fe_sqr<F>(xx, acc.x, md);
   fe_dbl(m, xx);
   fe_add(m, m, xx);
+  fe_carry(m);
   fe_sqr<F>(mm, m, md);
   fe_dbl(t, s);
-  fe_mul<F>(t2, w, acc.y, md);
   fe_sub(acc.x, mm, t, F::BIAS4_29);
   fe_carry(acc.x);
   fe_sub(d, s, acc.x, F::BIAS8_29);
-  fe_mul<F>(t1, m, d, md);
-  fe_sub(acc.y, t1, t2, F::BIAS2_28);
-  fe_carry(acc.y);
+  fe_carry(d);
+  fe_neg(nw, w, F::BIAS2_28);
+  fe_mul2<F>(acc.y, m, d, y1, nw, md);
   fe_mul<F>(acc.zz, v, acc.zz, md);
   fe_mul<F>(acc.zzz, w, acc.zzz, md);
 }

@@ -11,6 +11,9 @@ static void msm_check_fail(const char* file, int line, const char* cond) {
   if (g_check_failures++ == 0) snprintf(g_first_failure, sizeof g_first_failure, "%s:%d %s", file, line, cond);
 }
 #define MSM_CHECK(cond) do { if (!(cond)) msm_check_fail(__FILE__, __LINE__, #cond); } while (0)
+#define MSM_CHECK_COL_BEGIN() unsigned __int128 chk_col_ = col
+#define MSM_CHECK_COL_ADD(x) chk_col_ += (x)
+#define MSM_CHECK_COL_END(col) MSM_CHECK(chk_col_ == (unsigned __int128)(col))
 
 #include "host_curve.hpp"
 
@@ -28,6 +31,29 @@ static void t_fe_mul(const uint8_t* a, const uint8_t* b, uint8_t* out) {
   fe_mul<F>(z, x, y, md);
   fe_to_abi<F>(wo, z, md);
   memcpy(out, wo, 48);
+}
+
+template <class F>
+static void t_fe_sqr(const uint8_t* a, uint8_t* out) {
+  Modulus<F> md;
+  Fe x, z;
+  uint32_t wa[12], wo[12];
+  memcpy(wa, a, 48);
+  fe_from_abi<F>(x, wa, md);
+  fe_sqr<F>(z, x, md);
+  fe_to_abi<F>(wo, z, md);
+  memcpy(out, wo, 48);
+}
+
+// worst-case limbs for the column bounds: every limb 2^30 - 1 (the largest a multiply may see); only the checker matters
+template <class F>
+static void t_fe_extreme(int /*unused*/) {
+  Modulus<F> md;
+  Fe x, z;
+  for (int i = 0; i < NL - 1; i++) x.v[i] = (1u << 30) - 1;
+  x.v[NL - 1] = F::P[NL - 1] * 16;  // keeps the VALUE below 32p while every other limb sits at its bound
+  fe_mul<F>(z, x, x, md);
+  fe_sqr<F>(z, x, md);
 }
 
 template <class F>
@@ -125,6 +151,8 @@ long ht_check_failures(void) { return g_check_failures; }
 const char* ht_first_failure(void) { return g_first_failure; }
 void ht_reset_checks(void) { g_check_failures = 0; g_first_failure[0] = 0; }
 int ht_fe_mul(int curve, const uint8_t* a, const uint8_t* b, uint8_t* out) { DISPATCH(curve, t_fe_mul, a, b, out) }
+int ht_fe_sqr(int curve, const uint8_t* a, uint8_t* out) { DISPATCH(curve, t_fe_sqr, a, out) }
+int ht_fe_extreme(int curve) { DISPATCH(curve, t_fe_extreme, 0) }
 int ht_fe_roundtrip(int curve, const uint8_t* a, uint8_t* out) { DISPATCH(curve, t_fe_roundtrip, a, out) }
 int ht_fe_inv(int curve, const uint8_t* a, uint8_t* out) { DISPATCH(curve, t_fe_inv, a, out) }
 int ht_madd_chain(int curve, const uint8_t* pts, size_t stride, const uint8_t* neg, size_t n, uint8_t* out) { DISPATCH(curve, t_madd_chain, pts, stride, neg, n, out) }

@@ -143,7 +143,7 @@ struct mi355_msm_ctx {
     uint32_t K = opt_lane_entries ? (uint32_t)opt_lane_entries : (uint32_t)std::min<uint64_t>(128, std::max<uint64_t>(8, p.entries >> 20));
     p.K = (K + 3) & ~3u;
     p.nlanes = ceil_div(p.entries, p.K);
-    p.segK = opt_seg_entries ? (uint32_t)opt_seg_entries : 8;
+    p.segK = opt_seg_entries >= 4 ? (uint32_t)opt_seg_entries : 8;
     uint64_t nb = (uint64_t)p.windows * p.half;
     uint32_t l0 = nb > (1u << 18) ? ilog2_floor(nb >> 18) : 0;
     p.logL0 = std::min<uint32_t>(7, std::max<uint32_t>(3, l0));
@@ -263,6 +263,7 @@ void run_chunk(mi355_msm_ctx* ctx, const uint32_t* d_scalars, size_t base0, size
   if (p.nlanes > 1) {
     for (;;) {
       uint32_t nl = ceil_div(n_in, p.segK);
+      if (nl > 1 && 2 * (uint64_t)nl >= n_in) bad_arg("fragment merge would not shrink (%u slots, fan-in %u)", n_in, p.segK);
       SegOut o{ctx->buckets.as<XyzzDev>(), ctx->slots[cur ^ 1].as<XyzzDev>(), ctx->slot_keys[cur ^ 1].as<uint32_t>()};
       launch_segreduce<F>(ctx->slots[cur].as<XyzzDev>(), ctx->slot_keys[cur].as<uint32_t>(), n_in, p.segK, o, nl, st);
       if (nl == 1) break;
@@ -463,7 +464,8 @@ RustError mi355_msm_set_option(mi355_msm_ctx* ctx, const char* key, long value) 
       if (value < 0 || value > (1L << 27)) bad_arg("max_chunk %ld out of range [1, 2^27]", value);
       ctx->opt_max_chunk = value;
     } else if (k == "seg_entries") {
-      if (value != 0 && (value < 2 || value > 4096)) bad_arg("seg_entries %ld out of range", value);
+      // fan-in K maps n slots to 2*ceil(n/K); that only shrinks for K >= 4
+      if (value != 0 && (value < 4 || value > 4096)) bad_arg("seg_entries %ld out of range [4, 4096]", value);
       ctx->opt_seg_entries = value;
     } else {
       bad_arg("unknown option '%s'", key);

@@ -119,7 +119,7 @@ __device__ __forceinline__ void seg_flush(const SegOut& o, uint32_t t, uint32_t 
 // The hot kernel.  Lane t walks sorted entries [t*K, (t+1)*K): ~K mixed adds, one bucket store per run.
 // The next base is fetched before the current add so the gather latency hides under ~5k VALU ops.
 template <class F>
-__global__ void __launch_bounds__(256) k_accumulate(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
+__global__ void __launch_bounds__(256, 2) k_accumulate(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
                                                     uint32_t n_entries, uint32_t K, uint32_t sentinel,
                                                     const AffineDev* __restrict__ bases, SegOut out, uint32_t nlanes) {
   const uint32_t t = blockIdx.x * 256 + threadIdx.x;

@@ -84,7 +84,7 @@ RustError mi355_msm_run(mi355_msm_ctx* ctx, void* out_projective, const void* sc
 RustError mi355_msm_run_device(mi355_msm_ctx* ctx, void* out_projective, const void* d_scalars, size_t npoints,
                                size_t batches, void* stream);
 
-/* Tuning knobs ("window_bits", "lane_entries", "max_chunk", "seg_entries"); 0 restores the automatic choice.
+/* Tuning knobs ("window_bits" 2..24, "lane_entries", "max_chunk" <= 2^27, "seg_entries" >= 4); 0 restores the automatic choice.
  * Mirrors Matter Labs' runtime msm_configuration (P1A matter-labs/.../bellman-cuda.h:49-71). */
 RustError mi355_msm_set_option(mi355_msm_ctx* ctx, const char* key, long value);
 /* Per-stage device time (ms, HIP events on the launch stream) of the most recent run, summed over its chunks

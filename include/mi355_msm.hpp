@@ -1,0 +1,87 @@
+// mi355_msm.hpp -- header-only C++ mirror of the reference's Rust operator API over the C ABI (mi355_msm.h).
+//
+// The reference's host layer is Rust (P1A <entry>/src/lib.rs); this image has no Rust toolchain, so the host side above
+// the C ABI is C++ where the reference is compiled code (the brief's rule).  Same names, argument meaning and error
+// behaviour: `multi_scalar_mult_init(points) -> MultiScalarMultContext`, `multi_scalar_mult(ctx, points, scalars)
+// -> Vec<G::Projective>` with batch_size = scalars.len() / points.len() (P1A 6block/src/lib.rs:54-109); a non-zero error
+// code panics on the Rust side and throws here.  VariableBaseMSM::msm chops to the shorter slice
+// (ARK ec/src/msm/variable_base/mod.rs:44-53).
+#pragma once
+#include <cstdlib>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "mi355_msm.h"
+
+namespace mi355 {
+
+struct G1Affine {        // arkworks Affine image: size_of::<G1Affine>() == 104
+  uint64_t x[6], y[6];
+  uint8_t infinity;
+  uint8_t pad[7];
+};
+struct BigInteger256 {
+  uint64_t limbs[4];
+};
+struct G1Projective {    // arkworks Projective image (Jacobian), 144 bytes
+  uint64_t x[6], y[6], z[6];
+};
+static_assert(sizeof(G1Affine) == 104 && sizeof(BigInteger256) == 32 && sizeof(G1Projective) == 144, "ABI layouts");
+
+struct MsmError : std::runtime_error {
+  int code;
+  MsmError(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+inline void check(RustError e) {
+  if (e.code != 0) {
+    std::string msg = e.message ? e.message : "(no message)";
+    if (e.message) std::free(e.message);
+    throw MsmError(e.code, "mi355_msm error " + std::to_string(e.code) + ": " + msg);
+  }
+}
+
+struct MultiScalarMultContext {   // #[repr(C)] struct { context: *mut c_void }
+  mi355_msm_ctx* context = nullptr;
+  size_t npoints = 0;
+  MultiScalarMultContext() = default;
+  MultiScalarMultContext(const MultiScalarMultContext&) = delete;
+  MultiScalarMultContext& operator=(const MultiScalarMultContext&) = delete;
+  MultiScalarMultContext(MultiScalarMultContext&& o) noexcept : context(o.context), npoints(o.npoints) { o.context = nullptr; }
+  ~MultiScalarMultContext() {
+    if (context) {
+      RustError e = mi355_msm_destroy(context);
+      if (e.message) std::free(e.message);
+    }
+  }
+};
+
+inline MultiScalarMultContext multi_scalar_mult_init(const std::vector<G1Affine>& points, int curve = MI355_BLS12_377_G1) {
+  MultiScalarMultContext ctx;
+  check(mi355_msm_create(&ctx.context, curve, -1));
+  check(mi355_msm_set_bases(ctx.context, points.data(), points.size(), sizeof(G1Affine)));
+  ctx.npoints = points.size();
+  return ctx;
+}
+
+inline std::vector<G1Projective> multi_scalar_mult(MultiScalarMultContext& ctx, const std::vector<G1Affine>& points,
+                                                   const std::vector<BigInteger256>& scalars) {
+  const size_t npoints = points.size();
+  if (npoints != ctx.npoints) throw MsmError(-1, "multi_scalar_mult: context was initialised with a different point count");
+  if (npoints == 0 || scalars.size() % npoints != 0) throw MsmError(-1, "multi_scalar_mult: scalars is not a whole number of batches");
+  const size_t batch_size = scalars.size() / npoints;
+  std::vector<G1Projective> ret(batch_size);
+  check(mi355_msm_run(ctx.context, ret.data(), scalars.data(), npoints, batch_size));
+  return ret;
+}
+
+// VariableBaseMSM::msm_bigint shape: one stateless MSM, chopped to the shorter input.
+inline G1Projective msm(const std::vector<G1Affine>& bases, const std::vector<BigInteger256>& scalars, int curve = MI355_BLS12_377_G1) {
+  const size_t n = bases.size() < scalars.size() ? bases.size() : scalars.size();
+  G1Projective out;
+  check(mi355_msm(curve, &out, bases.data(), n, scalars.data(), sizeof(G1Affine)));
+  return out;
+}
+
+}  // namespace mi355

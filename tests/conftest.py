@@ -1,0 +1,75 @@
+import ctypes
+import json
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _ensure_built():
+    """CPU-side artefacts (oracle, host test lib, the HIP .so cross-compiled) are built once per session if missing."""
+    need = [os.path.join(ROOT, "oracle", "liboracle.so"),
+            os.path.join(ROOT, "2022-entries_amd", "libmsm_hosttest.so"),
+            os.path.join(ROOT, "2022-entries_amd", "libmi355msm.so")]
+    if not all(os.path.exists(p) for p in need):
+        import __graft_entry__ as g
+
+        g.build()
+
+
+@pytest.fixture(scope="session")
+def built():
+    _ensure_built()
+    return True
+
+
+@pytest.fixture(scope="session")
+def oracle(built):
+    lib = ctypes.CDLL(os.path.join(ROOT, "oracle", "liboracle.so"))
+    lib.oracle_msm.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t,
+                               ctypes.c_void_p, ctypes.c_int]
+    lib.oracle_msm_naive.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t,
+                                     ctypes.c_void_p]
+    lib.oracle_window_bits.argtypes = [ctypes.c_size_t]
+    return lib
+
+
+def oracle_msm(lib, cid, bases: bytes, scalars: bytes, n: int, threads: int = 0) -> bytes:
+    out = ctypes.create_string_buffer(144)
+    b = ctypes.create_string_buffer(bases, len(bases) or 1)
+    s = ctypes.create_string_buffer(scalars, len(scalars) or 1)
+    assert lib.oracle_msm(cid, b, 104, s, n, out, threads) == 0
+    return out.raw
+
+
+def oracle_msm_np(lib, cid, bases_np, scalars_np, n: int, threads: int = 0) -> bytes:
+    out = ctypes.create_string_buffer(144)
+    assert lib.oracle_msm(cid, bases_np.ctypes.data, 104, scalars_np.ctypes.data, n, out, threads) == 0
+    return out.raw
+
+
+@pytest.fixture(scope="session")
+def golden():
+    with open(os.path.join(ROOT, "tests", "golden", "msm_vectors.json")) as f:
+        return json.load(f)["cases"]
+
+
+@pytest.fixture(scope="session")
+def golden_constants():
+    with open(os.path.join(ROOT, "tests", "golden", "constants.json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="session")
+def ea(built):
+    import entries_amd
+
+    return entries_amd

@@ -1,0 +1,222 @@
+"""GPU: parity of the HIP path, called through the C ABI, against the CPU oracle and the golden vectors; then, at
+BASELINE.json's full sizes where the oracle is too slow, size-independent properties (linearity in the scalars,
+shard-and-fold consistency, the all-ones checksum).  Bit-exact everywhere: results are normalised projective images."""
+import ctypes
+import os
+import random
+
+import numpy as np
+import pytest
+
+import pymodel as m
+from conftest import oracle_msm, oracle_msm_np
+
+pytestmark = pytest.mark.gpu
+
+CURVES = [(0, m.BLS12_377_G1), (1, m.BLS12_381_G1)]
+R_TOP = {0: 0x12ab655e9a2ca556, 1: 0x73eda753299d7d48}
+
+
+def rand_scalars_np(cid, n, seed):
+    """uniform below r (top limb below r's top limb), 4 x u64 LE as uint8[n,32]"""
+    rng = np.random.default_rng(seed)
+    limbs = rng.integers(0, 1 << 64, size=(n, 4), dtype=np.uint64)
+    top = R_TOP[cid]
+    limbs[:, 3] %= np.uint64(top)
+    return limbs.view(np.uint8).reshape(n, 32)
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+
+    assert torch.cuda.is_available(), "GPU tests need a visible MI355X"
+    return torch
+
+
+def test_native_library_is_the_one_running(ea, torch_cuda):
+    """No silent fallback: the process has mapped the in-tree HIP library with gfx950 kernels."""
+    ea.load_library()
+    maps = open("/proc/self/maps").read()
+    assert "libmi355msm.so" in maps
+    assert "gfx950" in torch_cuda.cuda.get_device_properties(0).gcnArchName
+
+
+def test_golden_vectors(ea, golden, torch_cuda):
+    for case in golden:
+        bases, scalars = bytes.fromhex(case["bases"]), bytes.fromhex(case["scalars"])
+        ctx = ea.multi_scalar_mult_init(bases, case["curve"])
+        got = ea.multi_scalar_mult(ctx, bases, scalars)[0]
+        ctx.close()
+        assert got.hex() == case["expected"], f'{case["curve"]}/{case["name"]}'
+
+
+@pytest.mark.parametrize("cid,curve", CURVES)
+@pytest.mark.parametrize("npow", [10, 14, 16, 18])
+def test_random_vs_oracle(ea, oracle, torch_cuda, cid, curve, npow):
+    """msm_correctness (P1A combined-top-solutions/tests/msm.rs:15-40): accelerator == CPU MSM on random inputs,
+    2^15-style replicated bases, uniform scalars, several batches on one context."""
+    n = 1 << npow
+    bases = ea.generate_points(n, distinct=min(n, 1 << 11), seed=npow, curve=curve.name)
+    batches = 2 if npow <= 16 else 1
+    scalars = rand_scalars_np(cid, n * batches, seed=100 + npow)
+    ctx = ea.multi_scalar_mult_init(torch_cuda.from_numpy(bases).cuda(), curve.name)
+    got = ea.multi_scalar_mult(ctx, None, torch_cuda.from_numpy(scalars).cuda())
+    assert len(got) == batches
+    for b in range(batches):
+        exp = oracle_msm_np(oracle, cid, bases, np.ascontiguousarray(scalars[b * n:(b + 1) * n]), n)
+        assert got[b] == exp, f"{curve.name} 2^{npow} batch {b}"
+    # host-pointer entry points give the same bytes
+    ctx2 = ea.multi_scalar_mult_init(bases, curve.name)
+    assert ea.multi_scalar_mult(ctx2, bases, scalars) == got
+    ctx.close()
+    ctx2.close()
+
+
+@pytest.mark.parametrize("cid,curve", CURVES)
+def test_ragged_sizes_and_stateless_call(ea, oracle, torch_cuda, cid, curve):
+    rng = random.Random(11 + cid)
+    for n in (0, 1, 2, 3, 31, 32, 33, 255, 1000, 4097):
+        pts = m.random_points(curve, n, rng, max(1, n // 5)) if n else []
+        sc = m.random_scalars(curve, n, rng)
+        bases, scalars = curve.encode_affine_array(pts), m.encode_scalars(sc)
+        assert ea.msm(bases, scalars, curve.name) == oracle_msm(oracle, cid, bases, scalars, n), n
+    # VariableBaseMSM::msm chops to the shorter slice; msm_checked reports the shorter length
+    pts = m.random_points(curve, 20, rng)
+    sc = m.random_scalars(curve, 12, rng)
+    bases, scalars = curve.encode_affine_array(pts), m.encode_scalars(sc)
+    v = ea.VariableBaseMSM(curve.name)
+    assert v.msm(bases, scalars) == oracle_msm(oracle, cid, bases, scalars, 12)
+    assert v.msm_checked(bases, scalars) == 12
+
+
+@pytest.mark.parametrize("cid,curve", CURVES)
+def test_skewed_scalar_distributions(ea, oracle, torch_cuda, cid, curve):
+    """Hot buckets: equal scalars, tiny scalars, unit and zero scalars, top bits set, all-ones 256-bit values."""
+    n = 5000
+    bases = ea.generate_points(n, distinct=64, seed=3, curve=curve.name)
+    ctx = ea.multi_scalar_mult_init(bases, curve.name)
+    rng = np.random.default_rng(5)
+    variants = {
+        "all_equal": np.tile(rand_scalars_np(cid, 1, 9), (n, 1)),
+        "all_one": np.tile(np.array([1] + [0] * 31, dtype=np.uint8), (n, 1)),
+        "all_zero": np.zeros((n, 32), dtype=np.uint8),
+        "tiny": np.concatenate([rng.integers(0, 4, size=(n, 1), dtype=np.uint8), np.zeros((n, 31), dtype=np.uint8)], axis=1),
+        "two_values": np.where(rng.integers(0, 2, size=(n, 1)) == 1, rand_scalars_np(cid, 1, 1), rand_scalars_np(cid, 1, 2)).astype(np.uint8),
+        "r_minus_1": np.tile(np.frombuffer((curve.r - 1).to_bytes(32, "little"), dtype=np.uint8), (n, 1)),
+    }
+    for name, sc in variants.items():
+        sc = np.ascontiguousarray(sc)
+        got = ea.multi_scalar_mult(ctx, bases, sc)[0]
+        assert got == oracle_msm_np(oracle, cid, bases, sc, n), name
+    # full 256-bit scalars are exact integers for us; compare with the big-int model (arkworks ignores bits above the modulus size)
+    pts = [curve.decode_affine(bases[i].tobytes()) for i in range(40)]
+    ks = [(1 << 256) - 1 - i for i in range(40)]
+    got = ea.msm(bases[:40].tobytes(), m.encode_scalars(ks), curve.name)
+    assert got == curve.encode_projective_normalized(curve.msm_naive(pts, ks))
+    ctx.close()
+
+
+@pytest.mark.parametrize("cid,curve", CURVES)
+def test_tuning_knobs_do_not_change_results(ea, oracle, torch_cuda, cid, curve):
+    """window size, entries per lane, fragment fan-in and chunking are performance knobs only."""
+    n = 1 << 13
+    bases = ea.generate_points(n, distinct=300, seed=8, curve=curve.name)
+    scalars = rand_scalars_np(cid, n, 77)
+    exp = oracle_msm_np(oracle, cid, bases, scalars, n)
+    ctx = ea.multi_scalar_mult_init(bases, curve.name)
+    for opts in ({"window_bits": 2}, {"window_bits": 7}, {"window_bits": 11, "lane_entries": 4}, {"window_bits": 16, "lane_entries": 64},
+                 {"lane_entries": 1000}, {"seg_entries": 4}, {"seg_entries": 5}, {"seg_entries": 64}, {"max_chunk": 1000}, {"max_chunk": 4096, "window_bits": 9}):
+        for k in ("window_bits", "lane_entries", "seg_entries", "max_chunk"):
+            ctx.set_option(k, opts.get(k, 0))
+        assert ea.multi_scalar_mult(ctx, bases, scalars)[0] == exp, opts
+    with pytest.raises(ea.MsmError):
+        ctx.set_option("window_bits", 99)
+    with pytest.raises(ea.MsmError):
+        ctx.set_option("seg_entries", 2)      # a fan-in below 4 cannot shrink the fragment list
+    with pytest.raises(ea.MsmError):
+        ctx.set_option("nonsense", 1)
+    ctx.close()
+
+
+def test_prefix_run_and_errors(ea, oracle, torch_cuda):
+    c = m.BLS12_377_G1
+    n = 600
+    bases = ea.generate_points(n, distinct=50, seed=1, curve=c.name)
+    scalars = rand_scalars_np(0, n, 3)
+    ctx = ea.multi_scalar_mult_init(bases, c.name)
+    got = ctx.run(np.ascontiguousarray(scalars[:100]), npoints=100)[0]
+    assert got == oracle_msm_np(oracle, 0, bases, np.ascontiguousarray(scalars[:100]), 100)
+    with pytest.raises(ea.MsmError):
+        ctx.run(np.zeros((n + 1, 32), dtype=np.uint8), npoints=n + 1)   # more points than uploaded bases
+    with pytest.raises(ValueError):
+        ctx.run(np.zeros((n + 1, 32), dtype=np.uint8))                  # not a whole number of batches
+    ctx.close()
+
+
+# ---- full sizes: properties instead of the (too slow) oracle -------------------------------------------------
+
+def _big_case(ea, torch_cuda, curve, cid, npow, seed):
+    n = 1 << npow
+    distinct = 1 << 15
+    tile = ea.generate_points(distinct, distinct=distinct, seed=seed, curve=curve.name)
+    bases = torch_cuda.from_numpy(tile).cuda().repeat(n // distinct, 1).contiguous()
+    g = torch_cuda.Generator(device="cuda")
+    g.manual_seed(seed)
+    limbs = torch_cuda.randint(-(1 << 63), (1 << 63) - 1, (n, 4), dtype=torch_cuda.int64, device="cuda", generator=g)
+    limbs[:, 3] &= (1 << 59) - 1   # < 2^251: sums of two stay below 2^252 < r, no carries out of 256 bits
+    return tile, bases, limbs
+
+
+@pytest.mark.parametrize("cid,curve,npow", [(0, m.BLS12_377_G1, 22), (0, m.BLS12_377_G1, 26), (1, m.BLS12_381_G1, 26)])
+def test_full_size_properties(ea, oracle, torch_cuda, cid, curve, npow):
+    torch = torch_cuda
+    n = 1 << npow
+    tile, bases, k1 = _big_case(ea, torch, curve, cid, npow, seed=40 + npow + cid)
+    ctx = ea.MultiScalarMultContext(curve.name)
+    ctx.set_bases(bases)
+    as_bytes = lambda t: t.view(torch.uint8).reshape(-1, 32)
+    # (1) all-ones checksum: sum of the bases = (n / 2^15) * sum of the 2^15 distinct points (oracle at 2^15)
+    ones = torch.zeros((n, 4), dtype=torch.int64, device="cuda")
+    ones[:, 0] = 1
+    got_ones = ctx.run(as_bytes(ones))[0]
+    tile_sum = oracle_msm_np(oracle, cid, tile, np.tile(np.array([1] + [0] * 31, dtype=np.uint8), (1 << 15, 1)), 1 << 15)
+    mult = np.zeros((1, 32), dtype=np.uint8)
+    mult[0, :8] = np.frombuffer((n >> 15).to_bytes(8, "little"), dtype=np.uint8)
+    aff = tile_sum[:96] + b"\x00" * 8
+    assert got_ones == oracle_msm(oracle, cid, aff, mult.tobytes(), 1)
+    # (2) linearity: msm(k1) + msm(k2) == msm(k1 + k2)   (limb-wise int64 add with manual carries)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(999)
+    k2 = torch.randint(-(1 << 63), (1 << 63) - 1, (n, 4), dtype=torch.int64, device="cuda", generator=g)
+    k2[:, 3] &= (1 << 59) - 1
+    ksum = torch.empty_like(k1)
+    carry = torch.zeros(n, dtype=torch.int64, device="cuda")
+    for j in range(4):
+        a, b = k1[:, j], k2[:, j]
+        s = a + b
+        c1 = ((a < 0) & (b < 0)) | (((a < 0) | (b < 0)) & (s >= 0))      # unsigned overflow of a + b
+        s2 = s + carry
+        c2 = (s < 0) & (s2 >= 0) & (carry > 0)                             # unsigned overflow of + carry
+        ksum[:, j] = s2
+        carry = (c1 | c2).to(torch.int64)
+    r1 = ctx.run(as_bytes(k1))[0]
+    r2 = ctx.run(as_bytes(k2))[0]
+    r12 = ctx.run(as_bytes(ksum))[0]
+    assert ea.fold_partials([r1, r2], curve.name) == r12
+    # (3) shard-and-fold: the MSM over all pairs equals the fold of the MSMs over two disjoint halves
+    half = n // 2
+    lo = ctx.run(as_bytes(k1[:half].contiguous()), npoints=half)[0]
+    ctx_hi = ea.MultiScalarMultContext(curve.name)
+    ctx_hi.set_bases(bases[half:].contiguous())
+    hi = ctx_hi.run(as_bytes(k1[half:].contiguous()))[0]
+    assert ea.fold_partials([lo, hi], curve.name) == r1
+    # (4) spot parity on a prefix the oracle can do
+    sample = 1 << 16
+    sc = as_bytes(k1[:sample].contiguous()).cpu().numpy()
+    assert ctx.run(as_bytes(k1[:sample].contiguous()), npoints=sample)[0] == oracle_msm_np(
+        oracle, cid, np.ascontiguousarray(np.tile(tile, (sample >> 15, 1))), sc, sample)
+    # (5) idempotence / determinism
+    assert ctx.run(as_bytes(k1))[0] == r1
+    ctx.close()
+    ctx_hi.close()

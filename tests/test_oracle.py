@@ -1,0 +1,150 @@
+"""CPU: the oracle (C restatement of arkworks' VariableBaseMSM) against every pin we have:
+reference-held literal constants, the golden vectors (generated from pymodel and cross-checked against the reference's
+own C/C++ code at generation time), the independent Python model, and -- when oracle/_ref is present -- the reference's
+compiled HostCurve (BLS12-377) and yrrid C MSM (BLS12-381) directly."""
+import ctypes
+import os
+import random
+import subprocess
+import tempfile
+
+import pytest
+
+import pymodel as m
+from conftest import ROOT, oracle_msm
+
+CURVES = [(0, m.BLS12_377_G1), (1, m.BLS12_381_G1)]
+
+
+def _limbs_to_int(limbs):
+    return sum(int(x, 16) << (64 * i) for i, x in enumerate(limbs))
+
+
+@pytest.mark.parametrize("cid,curve", CURVES)
+def test_constants_match_reference_literals(oracle, golden_constants, cid, curve):
+    """p, R mod p, R^2 mod p, M0 as the reference's headers spell them (SPK ff/bls12-37{7,81}.hpp:10-25)."""
+    k = golden_constants[curve.name]
+    buf = ctypes.create_string_buffer(152)
+    assert oracle.oracle_field_consts(cid, buf) == 0
+    p = int.from_bytes(buf.raw[:48], "little")
+    one = int.from_bytes(buf.raw[48:96], "little")
+    rr = int.from_bytes(buf.raw[96:144], "little")
+    inv = int.from_bytes(buf.raw[144:152], "little")
+    assert p == _limbs_to_int(k["P"]) == curve.p
+    assert one == _limbs_to_int(k["ONE"])
+    assert rr == _limbs_to_int(k["RR"])
+    assert inv & 0xFFFFFFFF == int(k["M0"], 16)
+    assert _limbs_to_int(k["r"]) == curve.r
+    gx, gy = int(k["GX"]), int(k["GY"])
+    assert (gy * gy - gx * gx * gx - k["B"]) % p == 0          # generator on the curve
+    assert curve.mul(curve.r, (gx, gy)) is None                # and of order r (ARK test-templates/src/lib.rs:42-47)
+
+
+def test_window_rule(oracle):
+    """c = 3 below 32, else ln_without_floats(n) + 2 (ARK ec/src/msm/mod.rs:54-57); SURVEY 8(a1) values."""
+    assert oracle.oracle_window_bits(31) == 3
+    assert [oracle.oracle_window_bits(1 << k) for k in (16, 24, 26, 28)] == [13, 18, 19, 21]
+    for n in (32, 33, 1000, 65537):
+        assert oracle.oracle_window_bits(n) == m.ark_window_bits(n)
+
+
+def test_golden_vectors(oracle, golden):
+    for case in golden:
+        cid = m.CURVES[case["curve"]].curve_id
+        got = oracle_msm(oracle, cid, bytes.fromhex(case["bases"]), bytes.fromhex(case["scalars"]), case["n"])
+        assert got.hex() == case["expected"], case["name"]
+
+
+def test_edge_fixtures_are_infinity(golden):
+    """The FPGA harness edge cases have algebraically known answers: infinity (P1B msm_unit_tests.rs:21-183)."""
+    by = {(c["curve"], c["name"]): c for c in golden}
+    zero = m.BLS12_377_G1.encode_projective_normalized(None).hex()
+    for name in ("fpga_edge1", "alternating_pm_generator", "all_zero_scalars"):
+        assert by[("bls12_377_g1", name)]["expected"] == zero
+    # edge2 is s * (P + T - (P + T) + T) = s * T with T of order 2 and s = R mod r odd: the 2-torsion point itself
+    c = m.BLS12_377_G1
+    s = (1 << 256) % c.r
+    assert by[("bls12_377_g1", "fpga_edge2")]["expected"] == c.encode_projective_normalized(m.EDGE_T if s & 1 else None).hex()
+
+
+@pytest.mark.parametrize("cid,curve", CURVES)
+def test_naive_equals_pippenger(oracle, cid, curve):
+    """test_var_base_msm: naive sum k_i P_i == msm (ARK test-templates/src/msm.rs:7-38), here at 2^10."""
+    rng = random.Random(1000 + cid)
+    n = 1 << 10
+    pts = m.random_points(curve, n, rng, 64)
+    sc = m.random_scalars(curve, n, rng)
+    bases, scal = curve.encode_affine_array(pts), m.encode_scalars(sc)
+    fast = oracle_msm(oracle, cid, bases, scal, n)
+    out = ctypes.create_string_buffer(144)
+    assert oracle.oracle_msm_naive(cid, bases, 104, scal, n, out) == 0
+    assert out.raw == fast
+    assert fast == curve.encode_projective_normalized(curve.msm_pippenger(pts, sc))
+    # thread count must not matter
+    assert oracle_msm(oracle, cid, bases, scal, n, threads=1) == fast
+    assert oracle_msm(oracle, cid, bases, scal, n, threads=3) == fast
+
+
+@pytest.mark.parametrize("cid,curve", CURVES)
+def test_truncation_and_empty(oracle, cid, curve):
+    zero = curve.encode_projective_normalized(None)
+    assert oracle_msm(oracle, cid, b"", b"", 0) == zero
+    rng = random.Random(5)
+    pts = m.random_points(curve, 9, rng)
+    sc = m.random_scalars(curve, 9, rng)
+    # msm over the first 5 pairs only (ARK variable_base/mod.rs:72-74 chops to the shorter slice)
+    got = oracle_msm(oracle, cid, curve.encode_affine_array(pts), m.encode_scalars(sc), 5)
+    assert got == curve.encode_projective_normalized(curve.msm_naive(pts[:5], sc[:5]))
+
+
+REF377 = os.path.join(ROOT, "oracle", "_ref", "libref377.so")
+REF381 = os.path.join(ROOT, "oracle", "_ref", "yrrid381_msm")
+
+
+@pytest.mark.skipif(not os.path.exists(REF377), reason="oracle/_ref not built (needs /root/reference)")
+def test_against_reference_hostcurve_377(oracle):
+    """Field mul and a naive MSM through the reference's own HostCurve.cpp (CMB yrrid-ff-ec), built by oracle/Makefile."""
+    ref = ctypes.CDLL(REF377)
+    ref.ref377_msm_naive.restype = ctypes.c_int
+    c = m.BLS12_377_G1
+    rng = random.Random(77)
+    for _ in range(200):
+        a, b = rng.randrange(c.p), rng.randrange(c.p)
+        o1, o2 = ctypes.create_string_buffer(48), ctypes.create_string_buffer(48)
+        oracle.oracle_fp_mul(0, a.to_bytes(48, "little"), b.to_bytes(48, "little"), o1)
+        ref.ref377_fp_mul(a.to_bytes(48, "little"), b.to_bytes(48, "little"), o2)
+        assert o1.raw == o2.raw == ((a * b * pow(m.R, -1, c.p)) % c.p).to_bytes(48, "little")
+    for n in (1, 13, 40):
+        pts = m.random_points(c, n, rng, max(1, n // 3))
+        sc = m.random_scalars(c, n, rng)
+        if n > 3:
+            pts[2] = None
+        out = ctypes.create_string_buffer(144)
+        inf = ref.ref377_msm_naive(c.encode_affine_array(pts), ctypes.c_size_t(104), m.encode_scalars(sc), ctypes.c_size_t(n), out)
+        exp = oracle_msm(oracle, 0, c.encode_affine_array(pts), m.encode_scalars(sc), n)
+        assert (c.encode_projective_normalized(None) if inf else out.raw) == exp
+
+
+@pytest.mark.skipif(not os.path.exists(REF381), reason="oracle/_ref not built (needs /root/reference)")
+def test_against_reference_c_msm_381(oracle):
+    """A full MSM through the reference's C implementation (open-division/prize4-msm-wasm/yrrid/C/MSM.c)."""
+    c = m.BLS12_381_G1
+    rng = random.Random(381)
+    n = 48
+    pts = m.random_points(c, n, rng, 12)
+    sc = m.random_scalars(c, n, rng)
+    with tempfile.TemporaryDirectory() as d:
+        os.mkdir(os.path.join(d, "data"))
+        with open(os.path.join(d, "data", "points.hex"), "w") as f:
+            for P in pts:
+                f.write("%x\n%x\n" % P)
+        with open(os.path.join(d, "data", "scalars.hex"), "w") as f:
+            for k in sc:
+                f.write("%x\n" % k)
+        r = subprocess.run([REF381, str(n)], cwd=d, capture_output=True, text=True, check=True)
+    xs = [ln.split("=")[1].strip() for ln in r.stdout.splitlines() if ln.strip().startswith("x=")]
+    ys = [ln.split("=")[1].strip() for ln in r.stdout.splitlines() if ln.strip().startswith("y=")]
+    ref_pt = (int(xs[0], 16), int(ys[0], 16))
+    assert (int(xs[1], 16), int(ys[1], 16)) == ref_pt     # its simple and lambda MSMs agree
+    got = oracle_msm(oracle, 1, c.encode_affine_array(pts), m.encode_scalars(sc), n)
+    assert got == c.encode_projective_normalized(ref_pt)
