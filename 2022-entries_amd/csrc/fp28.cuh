@@ -149,39 +149,45 @@ MSM_HD void fe_mul2(Fe& r, const Fe& a, const Fe& b, const Fe& c, const Fe& d, c
   for (int i = 0; i < NL; i++) {
     MSM_CHECK(a.v[i] < (1u << 29) && b.v[i] < (1u << 29) && c.v[i] < (1u << 29) && d.v[i] < (1u << 29));
   }
+  // (two separately unrolled halves: one 27-trip loop is only partially unrolled by hipcc and then indexes
+  //  registers dynamically)
 #pragma unroll
-  for (int k = 0; k < 2 * NL - 1; k++) {
+  for (int k = 0; k < NL; k++) {
     MSM_CHECK_COL_BEGIN();
 #pragma unroll
-    for (int i = 0; i < NL; i++) {
-      const int j = k - i;
-      if (j >= 0 && j < NL) {
-        col += (uint64_t)a.v[i] * b.v[j];
-        col += (uint64_t)c.v[i] * d.v[j];
-        MSM_CHECK_COL_ADD((unsigned __int128)a.v[i] * b.v[j] + (unsigned __int128)c.v[i] * d.v[j]);
-      }
+    for (int i = 0; i <= k; i++) {
+      col += (uint64_t)a.v[i] * b.v[k - i];
+      col += (uint64_t)c.v[i] * d.v[k - i];
+      MSM_CHECK_COL_ADD((unsigned __int128)a.v[i] * b.v[k - i] + (unsigned __int128)c.v[i] * d.v[k - i]);
     }
-    if (k < NL) {
 #pragma unroll
-      for (int i = 0; i < k; i++) {
-        col += (uint64_t)m[i] * md.p[k - i];
-        MSM_CHECK_COL_ADD((unsigned __int128)m[i] * md.p[k - i]);
-      }
-      m[k] = ((uint32_t)col * F::M0) & LMASK;
-      col += (uint64_t)m[k] * md.p[0];
-      MSM_CHECK_COL_ADD((unsigned __int128)m[k] * md.p[0]);
-      MSM_CHECK_COL_END(col);
-      col >>= LB;
-    } else {
-#pragma unroll
-      for (int i = k - NL + 1; i < NL; i++) {
-        col += (uint64_t)m[i] * md.p[k - i];
-        MSM_CHECK_COL_ADD((unsigned __int128)m[i] * md.p[k - i]);
-      }
-      MSM_CHECK_COL_END(col);
-      t.v[k - NL] = (uint32_t)col & LMASK;
-      col >>= LB;
+    for (int i = 0; i < k; i++) {
+      col += (uint64_t)m[i] * md.p[k - i];
+      MSM_CHECK_COL_ADD((unsigned __int128)m[i] * md.p[k - i]);
     }
+    m[k] = ((uint32_t)col * F::M0) & LMASK;
+    col += (uint64_t)m[k] * md.p[0];
+    MSM_CHECK_COL_ADD((unsigned __int128)m[k] * md.p[0]);
+    MSM_CHECK_COL_END(col);
+    col >>= LB;
+  }
+#pragma unroll
+  for (int k = NL; k < 2 * NL - 1; k++) {
+    MSM_CHECK_COL_BEGIN();
+#pragma unroll
+    for (int i = k - NL + 1; i < NL; i++) {
+      col += (uint64_t)a.v[i] * b.v[k - i];
+      col += (uint64_t)c.v[i] * d.v[k - i];
+      MSM_CHECK_COL_ADD((unsigned __int128)a.v[i] * b.v[k - i] + (unsigned __int128)c.v[i] * d.v[k - i]);
+    }
+#pragma unroll
+    for (int i = k - NL + 1; i < NL; i++) {
+      col += (uint64_t)m[i] * md.p[k - i];
+      MSM_CHECK_COL_ADD((unsigned __int128)m[i] * md.p[k - i]);
+    }
+    MSM_CHECK_COL_END(col);
+    t.v[k - NL] = (uint32_t)col & LMASK;
+    col >>= LB;
   }
   MSM_CHECK(col < (1ull << 28));
   t.v[NL - 1] = (uint32_t)col;
@@ -202,41 +208,48 @@ MSM_HD void fe_sqr(Fe& r, const Fe& a, const Modulus<F>& md) {
     a2[i] = a.v[i] << 1;
   }
 #pragma unroll
-  for (int k = 0; k < 2 * NL - 1; k++) {
+  for (int k = 0; k < NL; k++) {
     MSM_CHECK_COL_BEGIN();
 #pragma unroll
-    for (int i = 0; i < NL; i++) {
-      const int j = k - i;
-      if (j > i && j < NL) {
-        col += (uint64_t)a.v[i] * a2[j];
-        MSM_CHECK_COL_ADD((unsigned __int128)a.v[i] * a2[j]);
-      }
+    for (int i = 0; 2 * i < k; i++) {
+      col += (uint64_t)a.v[i] * a2[k - i];
+      MSM_CHECK_COL_ADD((unsigned __int128)a.v[i] * a2[k - i]);
     }
     if ((k & 1) == 0) {
       col += (uint64_t)a.v[k / 2] * a.v[k / 2];
       MSM_CHECK_COL_ADD((unsigned __int128)a.v[k / 2] * a.v[k / 2]);
     }
-    if (k < NL) {
 #pragma unroll
-      for (int i = 0; i < k; i++) {
-        col += (uint64_t)m[i] * md.p[k - i];
-        MSM_CHECK_COL_ADD((unsigned __int128)m[i] * md.p[k - i]);
-      }
-      m[k] = ((uint32_t)col * F::M0) & LMASK;
-      col += (uint64_t)m[k] * md.p[0];
-      MSM_CHECK_COL_ADD((unsigned __int128)m[k] * md.p[0]);
-      MSM_CHECK_COL_END(col);
-      col >>= LB;
-    } else {
-#pragma unroll
-      for (int i = k - NL + 1; i < NL; i++) {
-        col += (uint64_t)m[i] * md.p[k - i];
-        MSM_CHECK_COL_ADD((unsigned __int128)m[i] * md.p[k - i]);
-      }
-      MSM_CHECK_COL_END(col);
-      t.v[k - NL] = (uint32_t)col & LMASK;
-      col >>= LB;
+    for (int i = 0; i < k; i++) {
+      col += (uint64_t)m[i] * md.p[k - i];
+      MSM_CHECK_COL_ADD((unsigned __int128)m[i] * md.p[k - i]);
     }
+    m[k] = ((uint32_t)col * F::M0) & LMASK;
+    col += (uint64_t)m[k] * md.p[0];
+    MSM_CHECK_COL_ADD((unsigned __int128)m[k] * md.p[0]);
+    MSM_CHECK_COL_END(col);
+    col >>= LB;
+  }
+#pragma unroll
+  for (int k = NL; k < 2 * NL - 1; k++) {
+    MSM_CHECK_COL_BEGIN();
+#pragma unroll
+    for (int i = k - NL + 1; 2 * i < k; i++) {
+      col += (uint64_t)a.v[i] * a2[k - i];
+      MSM_CHECK_COL_ADD((unsigned __int128)a.v[i] * a2[k - i]);
+    }
+    if ((k & 1) == 0) {
+      col += (uint64_t)a.v[k / 2] * a.v[k / 2];
+      MSM_CHECK_COL_ADD((unsigned __int128)a.v[k / 2] * a.v[k / 2]);
+    }
+#pragma unroll
+    for (int i = k - NL + 1; i < NL; i++) {
+      col += (uint64_t)m[i] * md.p[k - i];
+      MSM_CHECK_COL_ADD((unsigned __int128)m[i] * md.p[k - i]);
+    }
+    MSM_CHECK_COL_END(col);
+    t.v[k - NL] = (uint32_t)col & LMASK;
+    col >>= LB;
   }
   t.v[NL - 1] = (uint32_t)col;
   r = t;

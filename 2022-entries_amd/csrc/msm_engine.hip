@@ -107,6 +107,10 @@ int choose_window_bits(size_t n) {
   return best;
 }
 
+template <class F> struct ScalarFieldOf;
+template <> struct ScalarFieldOf<Bls12_377_Fq> { using type = Bls12_377_Fr; };
+template <> struct ScalarFieldOf<Bls12_381_Fq> { using type = Bls12_381_Fr; };
+
 struct Plan {
   uint32_t c, windows, half, sentinel, keybits;
   uint64_t entries;     // windows * n
@@ -128,7 +132,7 @@ struct mi355_msm_ctx {
   void* pinned = nullptr;  // window sums land here
   size_t pinned_bytes = 0;
   hipEvent_t ev[8] = {};
-  long opt_window_bits = 0, opt_lane_entries = 0, opt_max_chunk = 0, opt_seg_entries = 0;
+  long opt_window_bits = 0, opt_lane_entries = 0, opt_max_chunk = 0, opt_seg_entries = 0, opt_scalars_montgomery = 0;
   float last_ms[MI355_T_COUNT] = {};
   uint64_t last_info[8] = {};
 
@@ -245,8 +249,13 @@ void run_chunk(mi355_msm_ctx* ctx, const uint32_t* d_scalars, size_t base0, size
   const uint8_t* inf = ctx->inf.as<uint8_t>() + base0;
 
   HIP_OK(hipEventRecord(ctx->ev[0], st));
-  hipLaunchKernelGGL(k_digits, dim3(ceil_div(n, 256)), dim3(256), 0, st, d_scalars, inf, (uint32_t)n, p.c, p.windows,
-                     kbuf.current(), vbuf.current());
+  using FR = typename ScalarFieldOf<F>::type;
+  if (ctx->opt_scalars_montgomery)
+    hipLaunchKernelGGL((k_digits<FR, true>), dim3(ceil_div(n, 256)), dim3(256), 0, st, d_scalars, inf, (uint32_t)n, p.c,
+                       p.windows, kbuf.current(), vbuf.current());
+  else
+    hipLaunchKernelGGL((k_digits<FR, false>), dim3(ceil_div(n, 256)), dim3(256), 0, st, d_scalars, inf, (uint32_t)n, p.c,
+                       p.windows, kbuf.current(), vbuf.current());
   HIP_OK(hipGetLastError());
   HIP_OK(hipEventRecord(ctx->ev[1], st));
   HIP_OK(rocprim::radix_sort_pairs(ctx->sort_tmp.p, tmp_bytes, kbuf, vbuf, E, 0, p.keybits, st));
@@ -467,6 +476,8 @@ RustError mi355_msm_set_option(mi355_msm_ctx* ctx, const char* key, long value) 
       // fan-in K maps n slots to 2*ceil(n/K); that only shrinks for K >= 4
       if (value != 0 && (value < 4 || value > 4096)) bad_arg("seg_entries %ld out of range [4, 4096]", value);
       ctx->opt_seg_entries = value;
+    } else if (k == "scalars_montgomery") {
+      ctx->opt_scalars_montgomery = value != 0;
     } else {
       bad_arg("unknown option '%s'", key);
     }

@@ -85,6 +85,9 @@ RustError mi355_msm_run_device(mi355_msm_ctx* ctx, void* out_projective, const v
                                size_t batches, void* stream);
 
 /* Tuning knobs ("window_bits" 2..24, "lane_entries", "max_chunk" <= 2^27, "seg_entries" >= 4); 0 restores the automatic choice.
+ * "scalars_montgomery" = 1 makes every run treat the scalars as arkworks `Fr` values (Montgomery form, a*2^256 mod r)
+ * and convert them on the device first -- VariableBaseMSM::msm(bases, &[Fr]) = into_bigint + msm_bigint
+ * (ARK ec/src/msm/variable_base/mod.rs:48-53; sppark's `mont` flag SPK msm/pippenger.cuh:157-164).
  * Mirrors Matter Labs' runtime msm_configuration (P1A matter-labs/.../bellman-cuda.h:49-71). */
 RustError mi355_msm_set_option(mi355_msm_ctx* ctx, const char* key, long value);
 /* Per-stage device time (ms, HIP events on the launch stream) of the most recent run, summed over its chunks

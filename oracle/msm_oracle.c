@@ -40,16 +40,8 @@ typedef struct {
   fp_t one;      /* R mod p, R = 2^384 */
   fp_t r2;       /* R^2 mod p */
   int scalar_bits;
+  int nonresidue; /* Fp2 = Fp[u]/(u^2 - nonresidue): -5 for BLS12-377 (ARKC bls12_377/src/fields/fq2.rs:13), -1 for BLS12-381 */
 } field_t;
-
-typedef struct {
-  fp_t x, y, z;
-} jac_t;
-
-typedef struct {
-  fp_t x, y;
-  int inf;
-} aff_t;
 
 /* Moduli: ARKC bls12_377/src/fields/fq.rs:4, bls12_381/src/fields/fq.rs:4 (same limbs as SPK ff/bls12-377.hpp:10-14,
  * ff/bls12-381.hpp:10-14).  Scalar bit sizes: fr.rs:24 (253 bits), bls12_381 fr.rs:4 (255 bits). */
@@ -166,9 +158,10 @@ static void fp_inv(const field_t* f, fp_t* r, const fp_t* a) {
   *r = acc;
 }
 
-static void field_init(field_t* f, const uint64_t* p, int scalar_bits) {
+static void field_init(field_t* f, const uint64_t* p, int scalar_bits, int nonresidue) {
   memcpy(f->p.l, p, sizeof f->p.l);
   f->scalar_bits = scalar_bits;
+  f->nonresidue = nonresidue;
   uint64_t x = 1; /* Newton: x = p^-1 mod 2^64 */
   for (int i = 0; i < 6; i++) x *= 2 - p[0] * x;
   f->inv = (uint64_t)0 - x;
@@ -184,164 +177,11 @@ static void field_init(field_t* f, const uint64_t* p, int scalar_bits) {
 
 static void oracle_init(void) {
   if (g_init) return;
-  field_init(&g_fields[0], P377, 253);
-  field_init(&g_fields[1], P381, 255);
+  field_init(&g_fields[0], P377, 253, -5);
+  field_init(&g_fields[1], P381, 255, -1);
   g_init = 1;
 }
 
-/* ---- Jacobian group law (a = 0) -------------------------------------------------------------- */
-static void jac_zero(const field_t* f, jac_t* r) { /* short_weierstrass.rs:750-756: (1, 1, 0) */
-  r->x = f->one;
-  r->y = f->one;
-  memset(&r->z, 0, sizeof r->z);
-}
-
-static int jac_is_zero(const jac_t* a) { return fp_is_zero(&a->z); }
-
-/* short_weierstrass.rs:815-848 */
-static void jac_double(const field_t* f, jac_t* s) {
-  if (jac_is_zero(s)) return;
-  fp_t a, b, c, d, e, ff, t;
-  fp_sqr(f, &a, &s->x);         /* A = X1^2 */
-  fp_sqr(f, &b, &s->y);         /* B = Y1^2 */
-  fp_sqr(f, &c, &b);            /* C = B^2 */
-  fp_add(f, &t, &s->x, &b);     /* D = 2*((X1+B)^2 - A - C) */
-  fp_sqr(f, &t, &t);
-  fp_sub(f, &t, &t, &a);
-  fp_sub(f, &t, &t, &c);
-  fp_dbl(f, &d, &t);
-  fp_dbl(f, &t, &a);            /* E = 3*A */
-  fp_add(f, &e, &a, &t);
-  fp_sqr(f, &ff, &e);           /* F = E^2 */
-  fp_mul(f, &s->z, &s->z, &s->y); /* Z3 = 2*Y1*Z1 */
-  fp_dbl(f, &s->z, &s->z);
-  fp_dbl(f, &t, &d);            /* X3 = F - 2*D */
-  fp_sub(f, &s->x, &ff, &t);
-  fp_sub(f, &t, &d, &s->x);     /* Y3 = E*(D - X3) - 8*C */
-  fp_mul(f, &t, &t, &e);
-  fp_dbl(f, &c, &c);
-  fp_dbl(f, &c, &c);
-  fp_dbl(f, &c, &c);
-  fp_sub(f, &s->y, &t, &c);
-}
-
-/* short_weierstrass.rs:886-948 */
-static void jac_add_mixed(const field_t* f, jac_t* s, const aff_t* o) {
-  if (o->inf) return;
-  if (jac_is_zero(s)) {
-    s->x = o->x;
-    s->y = o->y;
-    s->z = f->one;
-    return;
-  }
-  fp_t z1z1, u2, s2, h, hh, i, j, r, v, t, t2;
-  fp_sqr(f, &z1z1, &s->z);
-  fp_mul(f, &u2, &z1z1, &o->x);
-  fp_mul(f, &s2, &s->z, &o->y);
-  fp_mul(f, &s2, &s2, &z1z1);
-  if (fp_eq(&s->x, &u2) && fp_eq(&s->y, &s2)) {
-    jac_double(f, s);
-    return;
-  }
-  fp_sub(f, &h, &u2, &s->x);    /* H = U2 - X1 */
-  fp_sqr(f, &hh, &h);           /* HH = H^2 */
-  fp_dbl(f, &i, &hh);           /* I = 4*HH */
-  fp_dbl(f, &i, &i);
-  fp_mul(f, &j, &h, &i);        /* J = H*I */
-  fp_sub(f, &r, &s2, &s->y);    /* r = 2*(S2 - Y1) */
-  fp_dbl(f, &r, &r);
-  fp_mul(f, &v, &s->x, &i);     /* V = X1*I */
-  fp_sqr(f, &t, &r);            /* X3 = r^2 - J - 2*V */
-  fp_sub(f, &t, &t, &j);
-  fp_dbl(f, &t2, &v);
-  fp_sub(f, &t, &t, &t2);
-  fp_t x3 = t;
-  fp_sub(f, &t, &v, &x3);       /* Y3 = r*(V - X3) - 2*Y1*J */
-  fp_mul(f, &t, &t, &r);
-  fp_mul(f, &t2, &s->y, &j);
-  fp_dbl(f, &t2, &t2);
-  fp_sub(f, &s->y, &t, &t2);
-  s->x = x3;
-  fp_add(f, &t, &s->z, &h);     /* Z3 = (Z1 + H)^2 - Z1Z1 - HH */
-  fp_sqr(f, &t, &t);
-  fp_sub(f, &t, &t, &z1z1);
-  fp_sub(f, &s->z, &t, &hh);
-}
-
-/* short_weierstrass.rs:979-1040 */
-static void jac_add(const field_t* f, jac_t* s, const jac_t* o) {
-  if (jac_is_zero(s)) {
-    *s = *o;
-    return;
-  }
-  if (jac_is_zero(o)) return;
-  fp_t z1z1, z2z2, u1, u2, s1, s2, h, i, j, r, v, t, t2;
-  fp_sqr(f, &z1z1, &s->z);
-  fp_sqr(f, &z2z2, &o->z);
-  fp_mul(f, &u1, &s->x, &z2z2);
-  fp_mul(f, &u2, &o->x, &z1z1);
-  fp_mul(f, &s1, &s->y, &o->z);
-  fp_mul(f, &s1, &s1, &z2z2);
-  fp_mul(f, &s2, &o->y, &s->z);
-  fp_mul(f, &s2, &s2, &z1z1);
-  if (fp_eq(&u1, &u2) && fp_eq(&s1, &s2)) {
-    jac_double(f, s);
-    return;
-  }
-  fp_sub(f, &h, &u2, &u1);      /* H = U2 - U1 */
-  fp_dbl(f, &i, &h);            /* I = (2H)^2 */
-  fp_sqr(f, &i, &i);
-  fp_mul(f, &j, &h, &i);        /* J = H*I */
-  fp_sub(f, &r, &s2, &s1);      /* r = 2*(S2 - S1) */
-  fp_dbl(f, &r, &r);
-  fp_mul(f, &v, &u1, &i);       /* V = U1*I */
-  fp_sqr(f, &t, &r);            /* X3 = r^2 - J - 2V */
-  fp_sub(f, &t, &t, &j);
-  fp_dbl(f, &t2, &v);
-  fp_sub(f, &t, &t, &t2);
-  fp_t x3 = t;
-  fp_sub(f, &t, &v, &x3);       /* Y3 = r*(V - X3) - 2*S1*J */
-  fp_mul(f, &t, &t, &r);
-  fp_mul(f, &t2, &s1, &j);
-  fp_dbl(f, &t2, &t2);
-  fp_t y3;
-  fp_sub(f, &y3, &t, &t2);
-  fp_add(f, &t, &s->z, &o->z);  /* Z3 = ((Z1 + Z2)^2 - Z1Z1 - Z2Z2)*H */
-  fp_sqr(f, &t, &t);
-  fp_sub(f, &t, &t, &z1z1);
-  fp_sub(f, &t, &t, &z2z2);
-  fp_mul(f, &s->z, &t, &h);
-  s->x = x3;
-  s->y = y3;
-}
-
-/* short_weierstrass.rs:1093-1115, written back as a normalised Projective image:
- * (x, y, 1) or the zero() triple (1, 1, 0). */
-static void jac_write_normalized(const field_t* f, const jac_t* a, uint8_t* out144) {
-  jac_t r;
-  if (jac_is_zero(a)) {
-    jac_zero(f, &r);
-  } else {
-    fp_t zi, zi2, zi3;
-    fp_inv(f, &zi, &a->z);
-    fp_sqr(f, &zi2, &zi);
-    fp_mul(f, &zi3, &zi2, &zi);
-    fp_mul(f, &r.x, &a->x, &zi2);
-    fp_mul(f, &r.y, &a->y, &zi3);
-    r.z = f->one;
-  }
-  memcpy(out144, r.x.l, 48);
-  memcpy(out144 + 48, r.y.l, 48);
-  memcpy(out144 + 96, r.z.l, 48);
-}
-
-static void aff_read(aff_t* a, const uint8_t* p) {
-  memcpy(a->x.l, p, 48);
-  memcpy(a->y.l, p + 48, 48);
-  a->inf = p[96] != 0; /* the flag byte is authoritative (short_weierstrass.rs:127-135) */
-}
-
-/* ---- msm_bigint (variable_base/mod.rs:68-162) -------------------------------------------------- */
 static int ark_log2_ceil(size_t n) { /* ark_std::log2: ceil(log2 n), 0 for n <= 1 */
   int lg = 0;
   while (((size_t)1 << lg) < n) lg++;
@@ -352,17 +192,6 @@ int oracle_window_bits(size_t size) { /* mod.rs:77-81 + msm/mod.rs:54-57 */
   if (size < 32) return 3;
   return ark_log2_ceil(size) * 69 / 100 + 2;
 }
-
-typedef struct {
-  const field_t* f;
-  const uint8_t* bases;
-  size_t stride;
-  const uint8_t* scalars;
-  size_t n;
-  int c;
-  int w_start;
-  jac_t result;
-} win_job_t;
 
 static int scalar_is_zero(const uint64_t* k) { return (k[0] | k[1] | k[2] | k[3]) == 0; }
 static int scalar_is_one(const uint64_t* k) { return k[0] == 1 && (k[1] | k[2] | k[3]) == 0; }
@@ -375,103 +204,147 @@ static uint64_t scalar_window(const uint64_t* k, int w_start, int c) {
   return v & (((uint64_t)1 << c) - 1);
 }
 
-static void* window_job(void* arg) {
-  win_job_t* j = (win_job_t*)arg;
-  const field_t* f = j->f;
-  size_t nb = ((size_t)1 << j->c) - 1;
-  jac_t* buckets = (jac_t*)malloc(nb * sizeof(jac_t));
-  for (size_t b = 0; b < nb; b++) jac_zero(f, &buckets[b]);
-  jac_t res;
-  jac_zero(f, &res);
-  for (size_t i = 0; i < j->n; i++) {
-    uint64_t k[4];
-    memcpy(k, j->scalars + 32 * i, 32);
-    if (scalar_is_zero(k)) continue; /* mod.rs:75 */
-    aff_t base;
-    aff_read(&base, j->bases + i * j->stride);
-    if (scalar_is_one(k)) { /* mod.rs:100-104 */
-      if (j->w_start == 0) jac_add_mixed(f, &res, &base);
-      continue;
-    }
-    uint64_t d = scalar_window(k, j->w_start, j->c);
-    if (d != 0) jac_add_mixed(f, &buckets[d - 1], &base); /* mod.rs:118-120 */
-  }
-  jac_t running;
-  jac_zero(f, &running);
-  for (size_t b = nb; b-- > 0;) { /* mod.rs:138-142 */
-    jac_add(f, &running, &buckets[b]);
-    jac_add(f, &res, &running);
-  }
-  free(buckets);
-  j->result = res;
+/* ---- Fp2 = Fp[u]/(u^2 - beta)  (ARK ff/src/fields/models/quadratic_extension.rs) ---------------------------- */
+typedef struct {
+  fp_t c0, c1;
+} fp2_t;
+
+static void fp2_add(const field_t* f, fp2_t* r, const fp2_t* a, const fp2_t* b) {
+  fp_add(f, &r->c0, &a->c0, &b->c0);
+  fp_add(f, &r->c1, &a->c1, &b->c1);
+}
+static void fp2_sub(const field_t* f, fp2_t* r, const fp2_t* a, const fp2_t* b) {
+  fp_sub(f, &r->c0, &a->c0, &b->c0);
+  fp_sub(f, &r->c1, &a->c1, &b->c1);
+}
+static void fp2_dbl(const field_t* f, fp2_t* r, const fp2_t* a) { fp2_add(f, r, a, a); }
+static int fp2_is_zero(const fp2_t* a) { return fp_is_zero(&a->c0) && fp_is_zero(&a->c1); }
+static int fp2_eq(const fp2_t* a, const fp2_t* b) { return fp_eq(&a->c0, &b->c0) && fp_eq(&a->c1, &b->c1); }
+
+/* r = beta * a for the small negative non-residues used here (-1, -5). */
+static void fp_mul_by_nonresidue(const field_t* f, fp_t* r, const fp_t* a) {
+  fp_t t = *a, acc;
+  memset(&acc, 0, sizeof acc);
+  for (int i = 0; i < -f->nonresidue; i++) fp_add(f, &acc, &acc, &t);
+  fp_neg(f, r, &acc);
+}
+
+/* quadratic_extension.rs:641-652 mul_assign (Karatsuba): v0 = a0 b0, v1 = a1 b1,
+ * c1 = (a0 + a1)(b0 + b1) - v0 - v1,  c0 = v0 + beta v1. */
+static void fp2_mul(const field_t* f, fp2_t* r, const fp2_t* a, const fp2_t* b) {
+  fp_t v0, v1, s, t, bv1;
+  fp_mul(f, &v0, &a->c0, &b->c0);
+  fp_mul(f, &v1, &a->c1, &b->c1);
+  fp_add(f, &s, &a->c0, &a->c1);
+  fp_add(f, &t, &b->c0, &b->c1);
+  fp_mul(f, &s, &s, &t);
+  fp_sub(f, &s, &s, &v0);
+  fp_sub(f, &s, &s, &v1);
+  fp_mul_by_nonresidue(f, &bv1, &v1);
+  fp_add(f, &r->c0, &v0, &bv1);
+  r->c1 = s;
+}
+static void fp2_sqr(const field_t* f, fp2_t* r, const fp2_t* a) { fp2_mul(f, r, a, a); }
+
+/* quadratic_extension.rs:323 inverse: (a0 - a1 u) / (a0^2 - beta a1^2). */
+static void fp2_inv(const field_t* f, fp2_t* r, const fp2_t* a) {
+  fp_t n0, n1, bn1, d, di;
+  fp_sqr(f, &n0, &a->c0);
+  fp_sqr(f, &n1, &a->c1);
+  fp_mul_by_nonresidue(f, &bn1, &n1);
+  fp_sub(f, &d, &n0, &bn1);
+  fp_inv(f, &di, &d);
+  fp_mul(f, &r->c0, &a->c0, &di);
+  fp_mul(f, &n0, &a->c1, &di);
+  fp_neg(f, &r->c1, &n0);
+}
+static void fp2_set_one(const field_t* f, fp2_t* r) {
+  r->c0 = f->one;
+  memset(&r->c1, 0, sizeof r->c1);
+}
+static void fp_set_one(const field_t* f, fp_t* r) { *r = f->one; }
+
+/* ---- instantiate the group law + MSM for G1 (Fp) and G2 (Fp2) ------------------------------------------------ */
+#define EL_T fp_t
+#define EL_BYTES 48
+#define EL_ADD fp_add
+#define EL_SUB fp_sub
+#define EL_DBL fp_dbl
+#define EL_MUL fp_mul
+#define EL_SQR fp_sqr
+#define EL_INV fp_inv
+#define EL_IS_ZERO fp_is_zero
+#define EL_EQ fp_eq
+#define EL_SET_ONE fp_set_one
+#define T(name) name##_g1
+#include "jac_msm_template.inc"
+#undef EL_T
+#undef EL_BYTES
+#undef EL_ADD
+#undef EL_SUB
+#undef EL_DBL
+#undef EL_MUL
+#undef EL_SQR
+#undef EL_INV
+#undef EL_IS_ZERO
+#undef EL_EQ
+#undef EL_SET_ONE
+#undef T
+
+#define EL_T fp2_t
+#define EL_BYTES 96
+#define EL_ADD fp2_add
+#define EL_SUB fp2_sub
+#define EL_DBL fp2_dbl
+#define EL_MUL fp2_mul
+#define EL_SQR fp2_sqr
+#define EL_INV fp2_inv
+#define EL_IS_ZERO fp2_is_zero
+#define EL_EQ fp2_eq
+#define EL_SET_ONE fp2_set_one
+#define T(name) name##_g2
+#include "jac_msm_template.inc"
+
+/* curve ids: 0 = BLS12-377 G1, 1 = BLS12-381 G1, 2 = BLS12-377 G2 (coordinates in Fp2, 200-byte Affine stride) */
+static const field_t* curve_field(int curve) {
+  oracle_init();
+  if (curve == 0 || curve == 2) return &g_fields[0];
+  if (curve == 1) return &g_fields[1];
   return NULL;
 }
 
-/* Returns 0 on success.  threads <= 0 means one thread per window. */
-int oracle_msm(int curve, const uint8_t* bases, size_t stride, const uint8_t* scalars, size_t n, uint8_t* out144,
-               int threads) {
-  if (curve < 0 || curve > 1) return -1;
-  oracle_init();
-  const field_t* f = &g_fields[curve];
-  int c = oracle_window_bits(n);
-  int nwin = (f->scalar_bits + c - 1) / c; /* (0..num_bits).step_by(c), mod.rs:87 */
-  win_job_t* jobs = (win_job_t*)calloc(nwin, sizeof(win_job_t));
-  pthread_t* tids = (pthread_t*)calloc(nwin, sizeof(pthread_t));
-  if (threads <= 0 || threads > nwin) threads = nwin;
-  for (int w = 0; w < nwin; w++) {
-    jobs[w].f = f;
-    jobs[w].bases = bases;
-    jobs[w].stride = stride;
-    jobs[w].scalars = scalars;
-    jobs[w].n = n;
-    jobs[w].c = c;
-    jobs[w].w_start = w * c;
-  }
-  for (int w0 = 0; w0 < nwin; w0 += threads) {
-    int w1 = w0 + threads < nwin ? w0 + threads : nwin;
-    if (threads == 1) {
-      window_job(&jobs[w0]);
-      continue;
-    }
-    for (int w = w0; w < w1; w++) pthread_create(&tids[w], NULL, window_job, &jobs[w]);
-    for (int w = w0; w < w1; w++) pthread_join(tids[w], NULL);
-  }
-  /* mod.rs:148-161: lowest + fold(rev windows[1..]) */
-  jac_t total;
-  jac_zero(f, &total);
-  for (int w = nwin - 1; w >= 1; w--) {
-    jac_add(f, &total, &jobs[w].result);
-    for (int i = 0; i < c; i++) jac_double(f, &total);
-  }
-  jac_t lowest = jobs[0].result;
-  jac_add(f, &lowest, &total);
-  jac_write_normalized(f, &lowest, out144);
-  free(jobs);
-  free(tids);
+int oracle_msm(int curve, const uint8_t* bases, size_t stride, const uint8_t* scalars, size_t n, uint8_t* out, int threads) {
+  const field_t* f = curve_field(curve);
+  if (!f) return -1;
+  return curve == 2 ? msm_impl_g2(f, bases, stride, scalars, n, out, threads) : msm_impl_g1(f, bases, stride, scalars, n, out, threads);
+}
+
+int oracle_msm_naive(int curve, const uint8_t* bases, size_t stride, const uint8_t* scalars, size_t n, uint8_t* out) {
+  const field_t* f = curve_field(curve);
+  if (!f) return -1;
+  return curve == 2 ? msm_naive_impl_g2(f, bases, stride, scalars, n, out) : msm_naive_impl_g1(f, bases, stride, scalars, n, out);
+}
+
+/* Fp2 multiplication on two 96-byte Montgomery images (c0 | c1); curve 1 uses BLS12-381's Fq2 (u^2 = -1), for which the
+ * reference holds known-answer tests (ARKC bls12_381/src/fields/tests.rs:1232-1394). */
+int oracle_fp2_mul(int curve, const uint8_t* a, const uint8_t* b, uint8_t* out) {
+  const field_t* f = curve_field(curve);
+  if (!f) return -1;
+  fp2_t x, y, z;
+  memcpy(&x, a, 96);
+  memcpy(&y, b, 96);
+  fp2_mul(f, &z, &x, &y);
+  memcpy(out, &z, 96);
   return 0;
 }
 
-/* sum k_i P_i by plain double-and-add: the property ARK test-templates/src/msm.rs:7-38 checks msm against. */
-int oracle_msm_naive(int curve, const uint8_t* bases, size_t stride, const uint8_t* scalars, size_t n, uint8_t* out144) {
-  if (curve < 0 || curve > 1) return -1;
-  oracle_init();
-  const field_t* f = &g_fields[curve];
-  jac_t total;
-  jac_zero(f, &total);
-  for (size_t i = 0; i < n; i++) {
-    uint64_t k[4];
-    memcpy(k, scalars + 32 * i, 32);
-    aff_t base;
-    aff_read(&base, bases + i * stride);
-    jac_t r;
-    jac_zero(f, &r);
-    for (int bit = 255; bit >= 0; bit--) {
-      jac_double(f, &r);
-      if ((k[bit >> 6] >> (bit & 63)) & 1) jac_add_mixed(f, &r, &base);
-    }
-    jac_add(f, &total, &r);
-  }
-  jac_write_normalized(f, &total, out144);
+int oracle_fp2_inv(int curve, const uint8_t* a, uint8_t* out) {
+  const field_t* f = curve_field(curve);
+  if (!f) return -1;
+  fp2_t x, z;
+  memcpy(&x, a, 96);
+  fp2_inv(f, &z, &x);
+  memcpy(out, &z, 96);
   return 0;
 }
 
@@ -504,14 +377,14 @@ int oracle_affine_add(int curve, const uint8_t* a104, const uint8_t* b104, uint8
   if (curve < 0 || curve > 1) return -1;
   oracle_init();
   const field_t* f = &g_fields[curve];
-  aff_t a, b;
-  aff_read(&a, a104);
-  aff_read(&b, b104);
-  jac_t s;
-  jac_zero(f, &s);
-  jac_add_mixed(f, &s, &a);
-  jac_add_mixed(f, &s, &b);
-  jac_write_normalized(f, &s, out144);
+  aff_t_g1 a, b;
+  aff_read_g1(&a, a104);
+  aff_read_g1(&b, b104);
+  jac_t_g1 s;
+  jac_zero_g1(f, &s);
+  jac_add_mixed_g1(f, &s, &a);
+  jac_add_mixed_g1(f, &s, &b);
+  jac_write_normalized_g1(f, &s, out144);
   return 0;
 }
 
@@ -523,34 +396,34 @@ int oracle_gen_points(int curve, const uint8_t* gen104, const uint8_t* h0_32, co
   if (curve < 0 || curve > 1) return -1;
   oracle_init();
   const field_t* f = &g_fields[curve];
-  aff_t g;
-  aff_read(&g, gen104);
-  jac_t acc, step;
+  aff_t_g1 g;
+  aff_read_g1(&g, gen104);
+  jac_t_g1 acc, step;
   const uint8_t* hs[2] = {h0_32, h1_32};
-  jac_t* outs[2] = {&acc, &step};
+  jac_t_g1* outs[2] = {&acc, &step};
   for (int s = 0; s < 2; s++) {
     uint64_t k[4];
     memcpy(k, hs[s], 32);
-    jac_t r;
-    jac_zero(f, &r);
+    jac_t_g1 r;
+    jac_zero_g1(f, &r);
     for (int bit = 255; bit >= 0; bit--) {
-      jac_double(f, &r);
-      if ((k[bit >> 6] >> (bit & 63)) & 1) jac_add_mixed(f, &r, &g);
+      jac_double_g1(f, &r);
+      if ((k[bit >> 6] >> (bit & 63)) & 1) jac_add_mixed_g1(f, &r, &g);
     }
     *outs[s] = r;
   }
   if (distinct > n) distinct = n;
   for (size_t i = 0; i < distinct; i++) {
     uint8_t img[144];
-    jac_write_normalized(f, &acc, img);
+    jac_write_normalized_g1(f, &acc, img);
     uint8_t* o = out + 104 * i;
     memset(o, 0, 104);
-    if (jac_is_zero(&acc)) {
+    if (jac_is_zero_g1(&acc)) {
       o[96] = 1;
     } else {
       memcpy(o, img, 96);
     }
-    jac_add(f, &acc, &step);
+    jac_add_g1(f, &acc, &step);
   }
   for (size_t have = distinct; have < n;) {
     size_t cp = have < n - have ? have : n - have;

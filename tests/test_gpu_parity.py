@@ -139,6 +139,27 @@ def test_tuning_knobs_do_not_change_results(ea, oracle, torch_cuda, cid, curve):
     ctx.close()
 
 
+@pytest.mark.parametrize("cid,curve", CURVES)
+def test_montgomery_form_scalars(ea, oracle, torch_cuda, cid, curve):
+    """VariableBaseMSM::msm(bases, &[Fr]): scalars arrive as Fr values (a * 2^256 mod r) and are converted on the device
+    (`into_bigint`, ARK ec/src/msm/variable_base/mod.rs:48-53); the result equals msm_bigint on the plain integers."""
+    rng = random.Random(21 + cid)
+    n = 3000
+    ks = m.random_scalars(curve, n, rng)
+    ks[0], ks[1], ks[2] = 0, 1, curve.r - 1
+    bases = ea.generate_points(n, distinct=100, seed=4, curve=curve.name)
+    plain = np.frombuffer(m.encode_scalars(ks), dtype=np.uint8).reshape(n, 32)
+    mont = np.frombuffer(m.encode_scalars([(k << 256) % curve.r for k in ks]), dtype=np.uint8).reshape(n, 32)
+    exp = oracle_msm_np(oracle, cid, bases, np.ascontiguousarray(plain), n)
+    ctx = ea.multi_scalar_mult_init(bases, curve.name)
+    assert ea.multi_scalar_mult(ctx, bases, plain)[0] == exp
+    ctx.set_option("scalars_montgomery", 1)
+    assert ea.multi_scalar_mult(ctx, bases, mont)[0] == exp
+    ctx.set_option("scalars_montgomery", 0)
+    assert ea.multi_scalar_mult(ctx, bases, plain)[0] == exp
+    ctx.close()
+
+
 def test_prefix_run_and_errors(ea, oracle, torch_cuda):
     c = m.BLS12_377_G1
     n = 600

@@ -148,3 +148,48 @@ def test_against_reference_c_msm_381(oracle):
     assert (int(xs[1], 16), int(ys[1], 16)) == ref_pt     # its simple and lambda MSMs agree
     got = oracle_msm(oracle, 1, c.encode_affine_array(pts), m.encode_scalars(sc), n)
     assert got == c.encode_projective_normalized(ref_pt)
+
+
+# ---- G2 / Fp2 ---------------------------------------------------------------------------------------------------
+
+def test_fq2_known_answers_from_reference(oracle):
+    """The reference's own Fq2 KATs (ARKC bls12_381/src/fields/tests.rs:1232-1392: square, mul, inverse) pin the Fp2
+    arithmetic the G2 path is built on (quadratic_extension.rs:641-652), for the oracle and for the Python model."""
+    import json
+
+    kat = json.load(open(os.path.join(ROOT, "tests", "golden", "fq2_kat_bls12_381.json")))
+    p = m.BLS12_381_G1.p
+    rinv = pow(m.R, -1, p)
+    enc = lambda c: ((int(c[0]) * m.R) % p).to_bytes(48, "little") + ((int(c[1]) * m.R) % p).to_bytes(48, "little")
+    dec = lambda b: [(int.from_bytes(b[:48], "little") * rinv) % p, (int.from_bytes(b[48:96], "little") * rinv) % p]
+    out = ctypes.create_string_buffer(96)
+    for c in kat["mul"]:
+        assert oracle.oracle_fp2_mul(1, enc(c["a"]), enc(c["b"]), out) == 0
+        assert dec(out.raw) == [int(x) for x in c["out"]]
+        r = m.Fp2(int(c["a"][0]), int(c["a"][1]), p, p - 1) * m.Fp2(int(c["b"][0]), int(c["b"][1]), p, p - 1)
+        assert [r.c0, r.c1] == [int(x) for x in c["out"]]
+    for c in kat["square"]:
+        oracle.oracle_fp2_mul(1, enc(c["a"]), enc(c["a"]), out)
+        assert dec(out.raw) == [int(x) for x in c["out"]]
+    for c in kat["inverse"]:
+        oracle.oracle_fp2_inv(1, enc(c["a"]), out)
+        assert dec(out.raw) == [int(x) for x in c["out"]]
+        r = m.Fp2(int(c["a"][0]), int(c["a"][1]), p, p - 1).inv()
+        assert [r.c0, r.c1] == [int(x) for x in c["out"]]
+
+
+def test_g2_oracle_vs_model():
+    """BLS12-377 G2 (Fq2 = Fq[u]/(u^2+5), b' = (0, 1551...906): ARKC bls12_377/src/fields/fq2.rs:13, curves/g2.rs:47-78)."""
+    lib = ctypes.CDLL(os.path.join(ROOT, "oracle", "liboracle.so"))
+    c = m.BLS12_377_G2
+    g = c.generator()
+    assert c.on_curve(g) and c.mul(c.r, g) is None
+    rng = random.Random(2)
+    for n in (1, 7, 33, 150):
+        pts = m.random_points(c, n, rng, max(1, n // 3))
+        sc = m.random_scalars(c, n, rng)
+        if n > 4:
+            sc[1], sc[2], pts[3] = 0, 1, None
+        out = ctypes.create_string_buffer(288)
+        assert lib.oracle_msm(2, c.encode_affine_array(pts), ctypes.c_size_t(200), m.encode_scalars(sc), ctypes.c_size_t(n), out, 0) == 0
+        assert out.raw == c.encode_projective_normalized(c.msm_pippenger(pts, sc) if n > 40 else c.msm_naive(pts, sc)), n

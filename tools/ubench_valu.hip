@@ -43,6 +43,14 @@ KERNEL(k_fma_f32, asm volatile("v_fma_f32 %0, %0, %4, %5\n\tv_fma_f32 %1, %1, %4
 KERNEL(k_mad_i32_i24, asm volatile("v_mad_i32_i24 %0, %0, %4, %5\n\tv_mad_i32_i24 %1, %1, %4, %5\n\tv_mad_i32_i24 %2, %2, %4, %5\n\tv_mad_i32_i24 %3, %3, %4, %5" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b), "v"(c));)
 KERNEL(k_cndmask, asm volatile("v_cndmask_b32 %0, %0, %4, vcc\n\tv_cndmask_b32 %1, %1, %4, vcc\n\tv_cndmask_b32 %2, %2, %4, vcc\n\tv_cndmask_b32 %3, %3, %4, vcc" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b) : "vcc");)
 KERNEL(k_alignbit, asm volatile("v_alignbit_b32 %0, %0, %4, 7\n\tv_alignbit_b32 %1, %1, %4, 7\n\tv_alignbit_b32 %2, %2, %4, 7\n\tv_alignbit_b32 %3, %3, %4, 7" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b));)
+KERNEL(k_lshrrev_b64, asm volatile("v_lshrrev_b64 %0, 28, %0\n\tv_lshrrev_b64 %1, 28, %1\n\tv_lshrrev_b64 %2, 28, %2\n\tv_lshrrev_b64 %3, 28, %3" : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3));)
+KERNEL(k_and_b32, asm volatile("v_and_b32 %0, %0, %4\n\tv_and_b32 %1, %1, %4\n\tv_and_b32 %2, %2, %4\n\tv_and_b32 %3, %3, %4" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b));)
+KERNEL(k_sub_u32, asm volatile("v_sub_u32 %0, %0, %4\n\tv_sub_u32 %1, %1, %4\n\tv_sub_u32 %2, %2, %4\n\tv_sub_u32 %3, %3, %4" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b));)
+KERNEL(k_lshrrev_b32, asm volatile("v_lshrrev_b32 %0, 3, %0\n\tv_lshrrev_b32 %1, 3, %1\n\tv_lshrrev_b32 %2, 3, %2\n\tv_lshrrev_b32 %3, 3, %3" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));)
+KERNEL(k_add3_u32, asm volatile("v_add3_u32 %0, %0, %4, %5\n\tv_add3_u32 %1, %1, %4, %5\n\tv_add3_u32 %2, %2, %4, %5\n\tv_add3_u32 %3, %3, %4, %5" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b), "v"(c));)
+KERNEL(k_and_or_b32, asm volatile("v_and_or_b32 %0, %0, %4, %5\n\tv_and_or_b32 %1, %1, %4, %5\n\tv_and_or_b32 %2, %2, %4, %5\n\tv_and_or_b32 %3, %3, %4, %5" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b), "v"(c));)
+KERNEL(k_cndmask_sgpr, asm volatile("v_cndmask_b32 %0, %0, %4, s[10:11]\n\tv_cndmask_b32 %1, %1, %4, s[10:11]\n\tv_cndmask_b32 %2, %2, %4, s[10:11]\n\tv_cndmask_b32 %3, %3, %4, s[10:11]" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b) : "s10", "s11");)
+KERNEL(k_mad_u64_u32_sconst, asm volatile("v_mad_u64_u32 %0, vcc, s20, %5, %0\n\tv_mad_u64_u32 %1, vcc, s20, %5, %1\n\tv_mad_u64_u32 %2, vcc, s20, %5, %2\n\tv_mad_u64_u32 %3, vcc, s20, %5, %3" : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3) : "v"(b), "v"(c) : "vcc", "s20");)
 KERNEL(k_mad_u64_u32_sgpr, asm volatile("v_mad_u64_u32 %0, s[10:11], %4, %5, %0\n\tv_mad_u64_u32 %1, s[12:13], %4, %5, %1\n\tv_mad_u64_u32 %2, s[10:11], %4, %5, %2\n\tv_mad_u64_u32 %3, s[12:13], %4, %5, %3" : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3) : "v"(b), "v"(c) : "s10", "s11", "s12", "s13");)
 
 typedef void (*kern_t)(uint32_t*, int);
@@ -64,7 +72,9 @@ int main(int argc, char** argv) {
     {"v_mul_hi_u32_u24", k_mul_hi_u32_u24},
     {"v_mad_u64_u32", k_mad_u64_u32}, {"v_mad_u64_u32(sgpr carry)", k_mad_u64_u32_sgpr}, {"v_mad_u64_u32 dependent", k_mad_u64_u32_dep},
     {"v_mad_u64_u32+v_addc (pair=2 instr)", k_mad_u64_u32_addc},
-    {"v_lshl_add_u64", k_lshl_add_u64}, {"v_fma_f64", k_fma_f64}, {"v_mul_f64", k_mul_f64}, {"v_add_f64", k_add_f64},
+    {"v_lshl_add_u64", k_lshl_add_u64}, {"v_lshrrev_b64", k_lshrrev_b64}, {"v_and_b32", k_and_b32}, {"v_sub_u32", k_sub_u32},
+    {"v_lshrrev_b32", k_lshrrev_b32}, {"v_add3_u32", k_add3_u32}, {"v_and_or_b32", k_and_or_b32}, {"v_cndmask_b32 (sgpr mask)", k_cndmask_sgpr},
+    {"v_mad_u64_u32 (sgpr operand)", k_mad_u64_u32_sconst}, {"v_fma_f64", k_fma_f64}, {"v_mul_f64", k_mul_f64}, {"v_add_f64", k_add_f64},
   };
   hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
   printf("%-40s %10s %14s %16s\n", "instruction", "ms", "cyc/wave-instr", "Glane-ops/s");
