@@ -8,6 +8,8 @@ from .msm import (  # noqa: F401
     MsmError,
     MultiScalarMultContext,
     VariableBaseMSM,
+    affine_stride,
+    projective_bytes,
     fold_partials,
     generate_points,
     library_path,

@@ -36,12 +36,32 @@ def hipcc() -> str:
     raise RuntimeError("hipcc not found: the MSM engine is HIP-only (no CPU fallback)")
 
 
+ENGINE_UNITS = ["msm_engine.hip", "kernels_377g1.hip", "kernels_381g1.hip", "kernels_377g2.hip"]
+
+
 def build_engine(force: bool = False) -> str:
+    """hipcc --offload-arch=gfx950: one object per translation unit (the per-curve kernel units take minutes each --
+    every field multiply is fully unrolled -- so they are compiled in parallel), then one link into libmi355msm.so."""
     out = os.path.join(PKG, "libmi355msm.so")
-    deps = glob.glob(os.path.join(CSRC, "*")) + glob.glob(os.path.join(ROOT, "include", "*.h"))
-    if force or _newer(out, deps):
-        _run([hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
-              "-o", out, os.path.join(CSRC, "msm_engine.hip")])
+    headers = [f for f in glob.glob(os.path.join(CSRC, "*")) if not f.endswith(".hip") and os.path.isfile(f)]
+    headers += glob.glob(os.path.join(ROOT, "include", "*.h"))
+    objdir = os.path.join(PKG, "build")
+    os.makedirs(objdir, exist_ok=True)
+    cc = hipcc()
+    jobs, objs = [], []
+    for unit in ENGINE_UNITS:
+        src = os.path.join(CSRC, unit)
+        obj = os.path.join(objdir, unit.replace(".hip", ".o"))
+        objs.append(obj)
+        if force or _newer(obj, headers + [src]):
+            cmd = [cc, "--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-c", src, "-o", obj]
+            print("+", " ".join(cmd), flush=True)
+            jobs.append((unit, subprocess.Popen(cmd)))
+    failed = [unit for unit, pr in jobs if pr.wait() != 0]
+    if failed:
+        raise RuntimeError("hipcc failed for " + ", ".join(failed))
+    if force or jobs or _newer(out, objs):
+        _run([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)
     return out
 
 

@@ -15,184 +15,285 @@
 
 namespace msm {
 
-struct Affine {
-  Fe x, y;
+// Points are generic over the coordinate element type: Fe for G1 (Fp), Fe2 for G2 (Fp2).
+template <class T>
+struct AffineT {
+  T x, y;
 };
 
-struct Xyzz {
-  Fe x, y, zz, zzz;
+template <class T>
+struct XyzzT {
+  T x, y, zz, zzz;
 };
 
+using Affine = AffineT<Fe>;
+using Xyzz = XyzzT<Fe>;
+
+// ---- coordinate-field policies -------------------------------------------------------------------------------
+// Every curve function below is written against this interface; contracts (limb / value bounds) are those of fp28.cuh:
+//   mul/sqr inputs: limbs < 2^30, values <= 18p (what the formulas produce);  outputs: class M per component.
+//   mul2(r, a, b, c, d) = a*b + c*d with all limbs < 2^29; output limbs < 2^28 + 16, value < 4p per component.
 template <class F>
-MSM_HD void xyzz_set_inf(Xyzz& r) {
-  fe_zero(r.x);
-  fe_zero(r.y);
-  fe_zero(r.zz);
-  fe_zero(r.zzz);
+struct FpEl {
+  using Fld = F;
+  using T = Fe;
+  using Md = Modulus<F>;
+  static MSM_HD void mul(T& r, const T& a, const T& b, const Md& md) { fe_mul<F>(r, a, b, md); }
+  static MSM_HD void sqr(T& r, const T& a, const Md& md) { fe_sqr<F>(r, a, md); }
+  static MSM_HD void mul2(T& r, const T& a, const T& b, const T& c, const T& d, const Md& md) { fe_mul2<F>(r, a, b, c, d, md); }
+  static MSM_HD void add(T& r, const T& a, const T& b) { fe_add(r, a, b); }
+  static MSM_HD void dbl(T& r, const T& a) { fe_dbl(r, a); }
+  static MSM_HD void sub(T& r, const T& a, const T& b, const uint32_t (&bias)[NL]) { fe_sub(r, a, b, bias); }
+  static MSM_HD void neg(T& r, const T& b, const uint32_t (&bias)[NL]) { fe_neg(r, b, bias); }
+  static MSM_HD void carry(T& r) { fe_carry(r); }
+  static MSM_HD bool is_zero_M(const T& a) { return fe_is_zero_M<F>(a); }
+  static MSM_HD void cmov(T& r, const T& a, bool take) { fe_cmov(r, a, take); }
+  static MSM_HD void set_one(T& r) { fe_set(r, F::ONE); }
+  static MSM_HD void zero(T& r) { fe_zero(r); }
+  // ABI images: 12 u32 words per coordinate (x*2^384 mod p, canonical)
+  static constexpr int WORDS = 12;
+  static constexpr int ACC_WAVES = 2;   // k_accumulate: <= 256 VGPRs, two waves per SIMD saturate VALU issue
+  static MSM_HD void from_abi(T& r, const uint32_t* w, const Md& md) { fe_from_abi<F>(r, w, md); }
+  static MSM_HD void to_abi(uint32_t* w, const T& a, const Md& md) { fe_to_abi<F>(w, a, md); }
+  static MSM_HD void reduce(T& r) { fe_reduce<F>(r); }
+};
+
+struct Fe2 {
+  Fe c0, c1;
+};
+
+// Fp2 = Fp[u]/(u^2 - BETA) with a small negative BETA (-5 for BLS12-377: ARKC bls12_377/src/fields/fq2.rs:13).
+// (a0 + a1 u)(b0 + b1 u) = (a0 b0 + a1 (BETA b1)) + (a0 b1 + a1 b0) u: two fused dual products, i.e. 4 limb products and
+// 2 Montgomery reductions -- the same multiply count as Karatsuba (quadratic_extension.rs:641-652) but both components
+// come out class M, which keeps every bound of the Fp schedule valid component-wise.
+template <class F, int NEG_BETA>
+struct Fp2El {
+  using Fld = F;
+  using T = Fe2;
+  using Md = Modulus<F>;
+  static MSM_HD void mul(T& r, const T& a, const T& b, const Md& md) {
+    Fe a0 = a.c0, a1 = a.c1, b0 = b.c0, b1 = b.c1, t;
+    fe_carry(a0);
+    fe_carry(a1);
+    fe_carry(b0);
+    fe_weak_reduce<F>(b1);                 // < 3p, normalized: NEG_BETA * b1 stays below 16p
+    Fe s;
+#pragma unroll
+    for (int i = 0; i < NL; i++) s.v[i] = b1.v[i] * (uint32_t)NEG_BETA;   // limbs < 5 * 2^28
+    fe_neg(t, s, F::BIAS16_31);            // BETA*b1 as (p, 16p], limbs < 2^31 + 2^28
+    fe_carry(t);
+    Fe c0, c1;
+    fe_mul2<F>(c0, a0, b0, a1, t, md);     // <= 18p*18p + 18p*16p < 2^10 p^2
+    fe_mul2<F>(c1, a0, b1, a1, b0, md);
+    r.c0 = c0;
+    r.c1 = c1;
+  }
+  static MSM_HD void sqr(T& r, const T& a, const Md& md) { mul(r, a, a, md); }
+  static MSM_HD void mul2(T& r, const T& a, const T& b, const T& c, const T& d, const Md& md) {
+    T t1, t2;
+    mul(t1, a, b, md);
+    mul(t2, c, d, md);
+    fe_add(r.c0, t1.c0, t2.c0);            // < 3p, limbs < 2^29: fine as a stored coordinate
+    fe_add(r.c1, t1.c1, t2.c1);
+    fe_carry(r.c0);
+    fe_carry(r.c1);
+  }
+  static MSM_HD void add(T& r, const T& a, const T& b) { fe_add(r.c0, a.c0, b.c0); fe_add(r.c1, a.c1, b.c1); }
+  static MSM_HD void dbl(T& r, const T& a) { fe_dbl(r.c0, a.c0); fe_dbl(r.c1, a.c1); }
+  static MSM_HD void sub(T& r, const T& a, const T& b, const uint32_t (&bias)[NL]) {
+    fe_sub(r.c0, a.c0, b.c0, bias);
+    fe_sub(r.c1, a.c1, b.c1, bias);
+  }
+  static MSM_HD void neg(T& r, const T& b, const uint32_t (&bias)[NL]) { fe_neg(r.c0, b.c0, bias); fe_neg(r.c1, b.c1, bias); }
+  static MSM_HD void carry(T& r) { fe_carry(r.c0); fe_carry(r.c1); }
+  static MSM_HD bool is_zero_M(const T& a) { return fe_is_zero_M<F>(a.c0) && fe_is_zero_M<F>(a.c1); }
+  static MSM_HD void cmov(T& r, const T& a, bool take) { fe_cmov(r.c0, a.c0, take); fe_cmov(r.c1, a.c1, take); }
+  static MSM_HD void set_one(T& r) { fe_set(r.c0, F::ONE); fe_zero(r.c1); }
+  static MSM_HD void zero(T& r) { fe_zero(r.c0); fe_zero(r.c1); }
+  // ABI images: c0 | c1, 12 u32 words each (arkworks QuadExtField { c0, c1 })
+  static constexpr int WORDS = 24;
+  static constexpr int ACC_WAVES = 1;   // an Fp2 XYZZ accumulator alone is 112 VGPRs: take the whole 512-entry file
+  static MSM_HD void from_abi(T& r, const uint32_t* w, const Md& md) {
+    fe_from_abi<F>(r.c0, w, md);
+    fe_from_abi<F>(r.c1, w + 12, md);
+  }
+  static MSM_HD void to_abi(uint32_t* w, const T& a, const Md& md) {
+    fe_to_abi<F>(w, a.c0, md);
+    fe_to_abi<F>(w + 12, a.c1, md);
+  }
+  static MSM_HD void reduce(T& r) { fe_reduce<F>(r.c0); fe_reduce<F>(r.c1); }
+};
+
+template <class E>
+MSM_HD void xyzz_set_inf(XyzzT<typename E::T>& r) {
+  E::zero(r.x);
+  E::zero(r.y);
+  E::zero(r.zz);
+  E::zero(r.zzz);
 }
 
-template <class F>
-MSM_HD bool xyzz_is_inf(const Xyzz& a) {
-  return fe_is_zero_M<F>(a.zz);
+template <class E>
+MSM_HD bool xyzz_is_inf(const XyzzT<typename E::T>& a) {
+  return E::is_zero_M(a.zz);
 }
 
 // r = (+/-) P as XYZZ with ZZ = ZZZ = 1.
-template <class F>
-MSM_HD void xyzz_from_affine(Xyzz& r, const Affine& p, bool negate) {
+template <class E>
+MSM_HD void xyzz_from_affine(XyzzT<typename E::T>& r, const AffineT<typename E::T>& p, bool negate) {
   r.x = p.x;
-  Fe ny;
-  fe_neg(ny, p.y, F::BIAS2_28);  // (0, 2p], limbs < 2^29
-  fe_carry(ny);
+  typename E::T ny;
+  E::neg(ny, p.y, E::Fld::BIAS2_28);  // (0, 2p], limbs < 2^29
+  E::carry(ny);
   r.y = p.y;
-  fe_cmov(r.y, ny, negate);
-  fe_set(r.zz, F::ONE);
-  fe_set(r.zzz, F::ONE);
+  E::cmov(r.y, ny, negate);
+  E::set_one(r.zz);
+  E::set_one(r.zzz);
 }
 
 // Shared tail of madd/add:  given P, R, PP = P^2 (already known non-zero mod p), the "first" point's
 // U1 (=X1 for madd) and S1 (=Y1), produce X3, Y3 and return PPP for the ZZ/ZZZ updates.
 //   X3 = R^2 - PPP - 2Q,  Y3 = R (Q - X3) - S1 PPP,  Q = U1 PP.
-template <class F>
-MSM_HD void add_tail(Fe& x3, Fe& y3, Fe& ppp, const Fe& P, Fe& R, const Fe& PP, const Fe& U1, const Fe& S1,
-                     const Modulus<F>& md) {
-  Fe q, r2, t, d, nppp;
-  fe_mul<F>(ppp, P, PP, md);   // M
-  fe_mul<F>(q, U1, PP, md);    // M
-  fe_carry(R);                 // limbs < 2^28 + 16 (value unchanged): lets R share a reduction below
-  fe_sqr<F>(r2, R, md);        // M
-  fe_dbl(t, q);                // < 4p, limbs < 2^29
-  fe_add(t, t, ppp);           // < 6p, limbs < 3*2^28
-  fe_sub(x3, r2, t, F::BIAS8_30);  // (2p, 10p), limbs < 2^28 + 2^30 + 2^28
-  fe_carry(x3);                // limbs < 2^28 + 16
-  fe_sub(d, q, x3, F::BIAS16_29);  // (6p, 18p), limbs < 2^30
-  fe_carry(d);                 // limbs < 2^28 + 16
-  fe_neg(nppp, ppp, F::BIAS2_28);  // -PPP as (0, 2p], limbs < 2^29
+template <class E>
+MSM_HD void add_tail(typename E::T& x3, typename E::T& y3, typename E::T& ppp, const typename E::T& P, typename E::T& R, const typename E::T& PP, const typename E::T& U1, const typename E::T& S1,
+                     const typename E::Md& md) {
+  typename E::T q, r2, t, d, nppp;
+  E::mul(ppp, P, PP, md);   // M
+  E::mul(q, U1, PP, md);    // M
+  E::carry(R);                 // limbs < 2^28 + 16 (value unchanged): lets R share a reduction below
+  E::sqr(r2, R, md);        // M
+  E::dbl(t, q);                // < 4p, limbs < 2^29
+  E::add(t, t, ppp);           // < 6p, limbs < 3*2^28
+  E::sub(x3, r2, t, E::Fld::BIAS8_30);  // (2p, 10p), limbs < 2^28 + 2^30 + 2^28
+  E::carry(x3);                // limbs < 2^28 + 16
+  E::sub(d, q, x3, E::Fld::BIAS16_29);  // (6p, 18p), limbs < 2^30
+  E::carry(d);                 // limbs < 2^28 + 16
+  E::neg(nppp, ppp, E::Fld::BIAS2_28);  // -PPP as (0, 2p], limbs < 2^29
   // Y3 = R*D - S1*PPP = R*D + S1*(-PPP): one reduction for both products; the result is class M
-  fe_mul2<F>(y3, R, d, S1, nppp, md);
+  E::mul2(y3, R, d, S1, nppp, md);
 }
 
 // acc = 2 * (x2, y2) from affine coordinates (mdbl-2008-s-1).  y2 may be a negated (lazy) value with
 // limbs < 2^29.  A 2-torsion point (y = 0) yields ZZ = 0, i.e. infinity, with no special case.
-template <class F>
-MSM_HD void xyzz_dbl_affine(Xyzz& acc, const Fe& x2, const Fe& y2, const Modulus<F>& md) {
-  Fe u, v, w, s, xx, m, mm, t, d, nw;
-  fe_dbl(u, y2);               // limbs < 2^30, value <= 4p
-  fe_sqr<F>(v, u, md);
-  fe_mul<F>(w, u, v, md);
-  fe_mul<F>(s, x2, v, md);
-  fe_sqr<F>(xx, x2, md);
-  fe_dbl(m, xx);
-  fe_add(m, m, xx);            // 3*XX: < 6p, limbs < 3*2^28
-  fe_carry(m);                 // limbs < 2^28 + 16
-  fe_sqr<F>(mm, m, md);
-  fe_dbl(t, s);                // < 4p, limbs < 2^29
-  fe_sub(acc.x, mm, t, F::BIAS4_29);  // (0, 6p)
-  fe_carry(acc.x);
-  fe_sub(d, s, acc.x, F::BIAS8_29);   // (2p, 10p), limbs < 2^30
-  fe_carry(d);
-  fe_neg(nw, w, F::BIAS2_28);
-  fe_mul2<F>(acc.y, m, d, y2, nw, md);  // M*(S - X3) - W*Y2   (y2 limbs < 2^29 also when negated)
+template <class E>
+MSM_HD void xyzz_dbl_affine(XyzzT<typename E::T>& acc, const typename E::T& x2, const typename E::T& y2, const typename E::Md& md) {
+  typename E::T u, v, w, s, xx, m, mm, t, d, nw;
+  E::dbl(u, y2);               // limbs < 2^30, value <= 4p
+  E::sqr(v, u, md);
+  E::mul(w, u, v, md);
+  E::mul(s, x2, v, md);
+  E::sqr(xx, x2, md);
+  E::dbl(m, xx);
+  E::add(m, m, xx);            // 3*XX: < 6p, limbs < 3*2^28
+  E::carry(m);                 // limbs < 2^28 + 16
+  E::sqr(mm, m, md);
+  E::dbl(t, s);                // < 4p, limbs < 2^29
+  E::sub(acc.x, mm, t, E::Fld::BIAS4_29);  // (0, 6p)
+  E::carry(acc.x);
+  E::sub(d, s, acc.x, E::Fld::BIAS8_29);   // (2p, 10p), limbs < 2^30
+  E::carry(d);
+  E::neg(nw, w, E::Fld::BIAS2_28);
+  E::mul2(acc.y, m, d, y2, nw, md);  // M*(S - X3) - W*Y2   (y2 limbs < 2^29 also when negated)
   acc.zz = v;
   acc.zzz = w;
 }
 
 // acc = 2 * acc (dbl-2008-s-1).
-template <class F>
-MSM_HD void xyzz_dbl(Xyzz& acc, const Modulus<F>& md) {
-  Fe u, v, w, s, xx, m, mm, t, d, nw, y1 = acc.y;
-  fe_dbl(u, acc.y);            // limbs < 2^29 + 32, value < 32p
-  fe_sqr<F>(v, u, md);
-  fe_mul<F>(w, u, v, md);
-  fe_mul<F>(s, acc.x, v, md);
-  fe_sqr<F>(xx, acc.x, md);
-  fe_dbl(m, xx);
-  fe_add(m, m, xx);
-  fe_carry(m);
-  fe_sqr<F>(mm, m, md);
-  fe_dbl(t, s);
-  fe_sub(acc.x, mm, t, F::BIAS4_29);
-  fe_carry(acc.x);
-  fe_sub(d, s, acc.x, F::BIAS8_29);
-  fe_carry(d);
-  fe_neg(nw, w, F::BIAS2_28);
-  fe_mul2<F>(acc.y, m, d, y1, nw, md);
-  fe_mul<F>(acc.zz, v, acc.zz, md);
-  fe_mul<F>(acc.zzz, w, acc.zzz, md);
+template <class E>
+MSM_HD void xyzz_dbl(XyzzT<typename E::T>& acc, const typename E::Md& md) {
+  typename E::T u, v, w, s, xx, m, mm, t, d, nw, y1 = acc.y;
+  E::dbl(u, acc.y);            // limbs < 2^29 + 32, value < 32p
+  E::sqr(v, u, md);
+  E::mul(w, u, v, md);
+  E::mul(s, acc.x, v, md);
+  E::sqr(xx, acc.x, md);
+  E::dbl(m, xx);
+  E::add(m, m, xx);
+  E::carry(m);
+  E::sqr(mm, m, md);
+  E::dbl(t, s);
+  E::sub(acc.x, mm, t, E::Fld::BIAS4_29);
+  E::carry(acc.x);
+  E::sub(d, s, acc.x, E::Fld::BIAS8_29);
+  E::carry(d);
+  E::neg(nw, w, E::Fld::BIAS2_28);
+  E::mul2(acc.y, m, d, y1, nw, md);
+  E::mul(acc.zz, v, acc.zz, md);
+  E::mul(acc.zzz, w, acc.zzz, md);
 }
 
 // acc += (+/-)(x2, y2)   (madd-2008-s; 8M + 2S on the common path).
 // `acc_inf` lets the caller pass what it already knows (a fresh run starts at infinity) so the common
 // first-element case costs no field work.  The affine point must not be infinity (filtered upstream:
 // the digit kernel emits no entries for bases flagged infinite).
-template <class F>
-MSM_HD void xyzz_madd(Xyzz& acc, const Affine& p, bool negate, bool acc_inf, const Modulus<F>& md) {
-  if (acc_inf || xyzz_is_inf<F>(acc)) {
-    xyzz_from_affine<F>(acc, p, negate);
+template <class E>
+MSM_HD void xyzz_madd(XyzzT<typename E::T>& acc, const AffineT<typename E::T>& p, bool negate, bool acc_inf, const typename E::Md& md) {
+  if (acc_inf || xyzz_is_inf<E>(acc)) {
+    xyzz_from_affine<E>(acc, p, negate);
     return;
   }
-  Fe y2, ny;
-  fe_neg(ny, p.y, F::BIAS2_28);  // limbs < 2^29 + 2^28... (bias limb < 2^29) -> < 2^30
+  typename E::T y2, ny;
+  E::neg(ny, p.y, E::Fld::BIAS2_28);  // limbs < 2^29 + 2^28... (bias limb < 2^29) -> < 2^30
   y2 = p.y;
-  fe_cmov(y2, ny, negate);
-  Fe u2, s2, P, R, PP;
-  fe_mul<F>(u2, p.x, acc.zz, md);
-  fe_mul<F>(s2, y2, acc.zzz, md);
-  fe_sub(P, u2, acc.x, F::BIAS16_29);  // (0, 18p), limbs < 2^30
-  fe_sub(R, s2, acc.y, F::BIAS16_29);
-  fe_sqr<F>(PP, P, md);
-  if (fe_is_zero_M<F>(PP)) {
+  E::cmov(y2, ny, negate);
+  typename E::T u2, s2, P, R, PP;
+  E::mul(u2, p.x, acc.zz, md);
+  E::mul(s2, y2, acc.zzz, md);
+  E::sub(P, u2, acc.x, E::Fld::BIAS16_29);  // (0, 18p), limbs < 2^30
+  E::sub(R, s2, acc.y, E::Fld::BIAS16_29);
+  E::sqr(PP, P, md);
+  if (E::is_zero_M(PP)) {
     // same x: either the same point (double) or its negative (infinity).
-    Fe r2;
-    fe_sqr<F>(r2, R, md);
-    if (fe_is_zero_M<F>(r2)) {
-      xyzz_dbl_affine<F>(acc, p.x, y2, md);
+    typename E::T r2;
+    E::sqr(r2, R, md);
+    if (E::is_zero_M(r2)) {
+      xyzz_dbl_affine<E>(acc, p.x, y2, md);
     } else {
-      xyzz_set_inf<F>(acc);
+      xyzz_set_inf<E>(acc);
     }
     return;
   }
-  Fe x3, y3, ppp;
-  add_tail<F>(x3, y3, ppp, P, R, PP, acc.x, acc.y, md);
+  typename E::T x3, y3, ppp;
+  add_tail<E>(x3, y3, ppp, P, R, PP, acc.x, acc.y, md);
   acc.x = x3;
   acc.y = y3;
-  fe_mul<F>(acc.zz, acc.zz, PP, md);
-  fe_mul<F>(acc.zzz, acc.zzz, ppp, md);
+  E::mul(acc.zz, acc.zz, PP, md);
+  E::mul(acc.zzz, acc.zzz, ppp, md);
 }
 
 // acc += b   (add-2008-s; 12M + 2S).
-template <class F>
-MSM_HD void xyzz_add(Xyzz& acc, const Xyzz& b, const Modulus<F>& md) {
-  if (xyzz_is_inf<F>(b)) return;
-  if (xyzz_is_inf<F>(acc)) {
+template <class E>
+MSM_HD void xyzz_add(XyzzT<typename E::T>& acc, const XyzzT<typename E::T>& b, const typename E::Md& md) {
+  if (xyzz_is_inf<E>(b)) return;
+  if (xyzz_is_inf<E>(acc)) {
     acc = b;
     return;
   }
-  Fe u1, u2, s1, s2, P, R, PP;
-  fe_mul<F>(u1, acc.x, b.zz, md);
-  fe_mul<F>(u2, b.x, acc.zz, md);
-  fe_mul<F>(s1, acc.y, b.zzz, md);
-  fe_mul<F>(s2, b.y, acc.zzz, md);
-  fe_sub(P, u2, u1, F::BIAS2_28);  // (0, 4p), limbs < 3*2^28
-  fe_sub(R, s2, s1, F::BIAS2_28);
-  fe_sqr<F>(PP, P, md);
-  if (fe_is_zero_M<F>(PP)) {
-    Fe r2;
-    fe_sqr<F>(r2, R, md);
-    if (fe_is_zero_M<F>(r2)) {
-      xyzz_dbl<F>(acc, md);
+  typename E::T u1, u2, s1, s2, P, R, PP;
+  E::mul(u1, acc.x, b.zz, md);
+  E::mul(u2, b.x, acc.zz, md);
+  E::mul(s1, acc.y, b.zzz, md);
+  E::mul(s2, b.y, acc.zzz, md);
+  E::sub(P, u2, u1, E::Fld::BIAS2_28);  // (0, 4p), limbs < 3*2^28
+  E::sub(R, s2, s1, E::Fld::BIAS2_28);
+  E::sqr(PP, P, md);
+  if (E::is_zero_M(PP)) {
+    typename E::T r2;
+    E::sqr(r2, R, md);
+    if (E::is_zero_M(r2)) {
+      xyzz_dbl<E>(acc, md);
     } else {
-      xyzz_set_inf<F>(acc);
+      xyzz_set_inf<E>(acc);
     }
     return;
   }
-  Fe x3, y3, ppp, t;
-  add_tail<F>(x3, y3, ppp, P, R, PP, u1, s1, md);
+  typename E::T x3, y3, ppp, t;
+  add_tail<E>(x3, y3, ppp, P, R, PP, u1, s1, md);
   acc.x = x3;
   acc.y = y3;
-  fe_mul<F>(t, acc.zz, b.zz, md);
-  fe_mul<F>(acc.zz, t, PP, md);
-  fe_mul<F>(t, acc.zzz, b.zzz, md);
-  fe_mul<F>(acc.zzz, t, ppp, md);
+  E::mul(t, acc.zz, b.zz, md);
+  E::mul(acc.zz, t, PP, md);
+  E::mul(t, acc.zzz, b.zzz, md);
+  E::mul(acc.zzz, t, ppp, md);
 }
 
 }  // namespace msm

@@ -310,6 +310,30 @@ MSM_HD void fe_normalize(Fe& r) {
   r.v[NL - 1] += c;
 }
 
+// Cheap partial reduction for lazy values: in  value < 32p, limbs < 2^31;  out  value < 3p, strictly normalized.
+// q = floor(top_limb / (p_top + 1)) under-estimates floor(value / p) by at most 2 (the multiply-shift division adds
+// one more unit of slack), so value - q*p stays non-negative and below 3p.  ~110 cheap ops, no multiplier chain.
+template <class F>
+MSM_HD void fe_weak_reduce(Fe& r) {
+  fe_normalize(r);
+  constexpr uint32_t PT = F::P[NL - 1];
+  constexpr uint32_t MAGIC = (uint32_t)((1ull << 32) / (PT + 1));
+  const uint32_t q = (uint32_t)(((uint64_t)r.v[NL - 1] * MAGIC) >> 32);
+  MSM_CHECK(q < 64);
+  int64_t c = 0;
+#pragma unroll
+  for (int i = 0; i < NL; i++) {
+    c += (int64_t)r.v[i] - (int64_t)((uint64_t)q * F::P[i]);
+    if (i < NL - 1) {
+      r.v[i] = (uint32_t)c & LMASK;
+      c >>= LB;
+    } else {
+      MSM_CHECK(c >= 0 && c < (1ll << 28));
+      r.v[i] = (uint32_t)c;
+    }
+  }
+}
+
 // a >= b on strictly normalized limbs.
 MSM_HD bool fe_geq(const Fe& a, const uint32_t (&b)[NL]) {
   bool ge = true;  // equal so far => a >= b

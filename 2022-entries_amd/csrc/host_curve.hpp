@@ -45,73 +45,119 @@ inline void fe_inv(Fe& r, const Fe& a, const Modulus<F>& md) {
   r = acc;
 }
 
-// arkworks Affine image (x, y Montgomery 6xu64 LE, infinity flag at byte 96) -> internal Affine.
-// The flag byte is authoritative (SURVEY section 8b: zero is (0,1,true) in ark 0.3 and (0,0,true) in 0.4).
+// Inverse in the coordinate field (host only).
 template <class F>
-inline bool affine_from_abi(Affine& out, const uint8_t* p, const Modulus<F>& md) {
-  uint32_t w[24];
-  memcpy(w, p, 96);
-  if (p[96] != 0) {
-    fe_zero(out.x);
-    fe_zero(out.y);
+inline void el_inv(Fe& r, const Fe& a, const Modulus<F>& md, FpEl<F>*) {
+  fe_inv<F>(r, a, md);
+}
+// (a0 + a1 u)^-1 = (a0 - a1 u) / (a0^2 - BETA a1^2)   (quadratic_extension.rs:323)
+template <class F, int NB>
+inline void el_inv(Fe2& r, const Fe2& a, const Modulus<F>& md, Fp2El<F, NB>*) {
+  Fe n0, n1, n, ni, t;
+  fe_sqr<F>(n0, a.c0, md);
+  fe_sqr<F>(n1, a.c1, md);
+  for (int i = 0; i < NL; i++) n.v[i] = n0.v[i] + n1.v[i] * (uint32_t)NB;   // a0^2 + NB a1^2, < 9p, limbs < 6*2^28
+  fe_carry(n);
+  Fe one;
+  fe_set(one, F::ONE);
+  fe_mul<F>(n, n, one, md);   // back to class M (value unchanged mod p: n * R * R^-1)
+  fe_inv<F>(ni, n, md);
+  fe_mul<F>(r.c0, a.c0, ni, md);
+  fe_mul<F>(t, a.c1, ni, md);
+  fe_neg(r.c1, t, F::BIAS2_28);
+  fe_carry(r.c1);
+}
+
+// arkworks Affine image (x, y in the ABI Montgomery radix, infinity flag after the two coordinates) -> internal Affine.
+// The flag byte is authoritative (SURVEY section 8b: zero is (0,1,true) in ark 0.3 and (0,0,true) in 0.4).
+template <class E>
+inline bool affine_from_abi(AffineT<typename E::T>& out, const uint8_t* p, const typename E::Md& md) {
+  constexpr int CB = E::WORDS * 4;
+  uint32_t w[2 * E::WORDS];
+  memcpy(w, p, 2 * CB);
+  if (p[2 * CB] != 0) {
+    E::zero(out.x);
+    E::zero(out.y);
     return true;
   }
-  fe_from_abi<F>(out.x, w, md);
-  fe_from_abi<F>(out.y, w + 12, md);
+  E::from_abi(out.x, w, md);
+  E::from_abi(out.y, w + E::WORDS, md);
   return false;
 }
 
 // XYZZ -> arkworks Projective image, normalised: (x, y, 1) or (1, 1, 0) for infinity
 // (ARK ec/src/models/short_weierstrass.rs:750-756), all in the ABI Montgomery radix.
-template <class F>
-inline void xyzz_to_projective_abi(uint8_t* out144, const Xyzz& a, const Modulus<F>& md) {
-  uint32_t w[36];
-  Fe one;
-  fe_set(one, F::ONE);
-  if (xyzz_is_inf<F>(a)) {
-    fe_to_abi<F>(w, one, md);
-    fe_to_abi<F>(w + 12, one, md);
-    memset(w + 24, 0, 48);
-    memcpy(out144, w, 144);
+template <class E>
+inline void xyzz_to_projective_abi(uint8_t* out, const XyzzT<typename E::T>& a, const typename E::Md& md) {
+  constexpr int CB = E::WORDS * 4;
+  uint32_t w[3 * E::WORDS];
+  typename E::T one;
+  E::set_one(one);
+  if (xyzz_is_inf<E>(a)) {
+    E::to_abi(w, one, md);
+    E::to_abi(w + E::WORDS, one, md);
+    memset(w + 2 * E::WORDS, 0, CB);
+    memcpy(out, w, 3 * CB);
     return;
   }
-  Fe t, ti, zzi, zzzi, x, y;
-  fe_mul<F>(t, a.zz, a.zzz, md);
-  fe_inv<F>(ti, t, md);
-  fe_mul<F>(zzi, ti, a.zzz, md);
-  fe_mul<F>(zzzi, ti, a.zz, md);
-  fe_mul<F>(x, a.x, zzi, md);
-  fe_mul<F>(y, a.y, zzzi, md);
-  fe_to_abi<F>(w, x, md);
-  fe_to_abi<F>(w + 12, y, md);
-  fe_to_abi<F>(w + 24, one, md);
-  memcpy(out144, w, 144);
+  typename E::T t, ti, zzi, zzzi, x, y;
+  E::mul(t, a.zz, a.zzz, md);
+  el_inv(ti, t, md, (E*)nullptr);
+  E::mul(zzi, ti, a.zzz, md);
+  E::mul(zzzi, ti, a.zz, md);
+  E::mul(x, a.x, zzi, md);
+  E::mul(y, a.y, zzzi, md);
+  E::to_abi(w, x, md);
+  E::to_abi(w + E::WORDS, y, md);
+  E::to_abi(w + 2 * E::WORDS, one, md);
+  memcpy(out, w, 3 * CB);
 }
 
 // arkworks Projective (Jacobian X, Y, Z) image -> XYZZ (X, Y, Z^2, Z^3).
-template <class F>
-inline void xyzz_from_projective_abi(Xyzz& out, const uint8_t* p144, const Modulus<F>& md) {
-  uint32_t w[36];
-  memcpy(w, p144, 144);
-  Fe z;
-  fe_from_abi<F>(out.x, w, md);
-  fe_from_abi<F>(out.y, w + 12, md);
-  fe_from_abi<F>(z, w + 24, md);
-  fe_sqr<F>(out.zz, z, md);
-  fe_mul<F>(out.zzz, out.zz, z, md);
+template <class E>
+inline void xyzz_from_projective_abi(XyzzT<typename E::T>& out, const uint8_t* p, const typename E::Md& md) {
+  constexpr int CB = E::WORDS * 4;
+  uint32_t w[3 * E::WORDS];
+  memcpy(w, p, 3 * CB);
+  typename E::T z;
+  E::from_abi(out.x, w, md);
+  E::from_abi(out.y, w + E::WORDS, md);
+  E::from_abi(z, w + 2 * E::WORDS, md);
+  E::sqr(out.zz, z, md);
+  E::mul(out.zzz, out.zz, z, md);
 }
 
 // result = sum_w 2^(c*w) * sums[w]   (window combine, high to low).
-template <class F>
-inline void fold_windows(Xyzz& acc, const Xyzz* sums, int windows, int c, const Modulus<F>& md) {
-  xyzz_set_inf<F>(acc);
+template <class E>
+inline void fold_windows(XyzzT<typename E::T>& acc, const XyzzT<typename E::T>* sums, int windows, int c, const typename E::Md& md) {
+  xyzz_set_inf<E>(acc);
   for (int w = windows - 1; w >= 0; w--) {
-    if (!xyzz_is_inf<F>(acc)) {
-      for (int i = 0; i < c; i++) xyzz_dbl<F>(acc, md);
+    if (!xyzz_is_inf<E>(acc)) {
+      for (int i = 0; i < c; i++) xyzz_dbl<E>(acc, md);
     }
-    xyzz_add<F>(acc, sums[w], md);
+    xyzz_add<E>(acc, sums[w], md);
   }
 }
+
+// ---- curve descriptors: coordinate field policy, scalar field, ABI sizes, generator -----------------------------
+struct Bls12_377_G1 {
+  using E = FpEl<Bls12_377_Fq>;
+  using FR = Bls12_377_Fr;
+  static void generator(AffineT<Fe>& g) { fe_set(g.x, Bls12_377_Fq::G1X); fe_set(g.y, Bls12_377_Fq::G1Y); }
+};
+struct Bls12_381_G1 {
+  using E = FpEl<Bls12_381_Fq>;
+  using FR = Bls12_381_Fr;
+  static void generator(AffineT<Fe>& g) { fe_set(g.x, Bls12_381_Fq::G1X); fe_set(g.y, Bls12_381_Fq::G1Y); }
+};
+struct Bls12_377_G2 {
+  using E = Fp2El<Bls12_377_Fq, 5>;
+  using FR = Bls12_377_Fr;
+  static void generator(AffineT<Fe2>& g) {
+    fe_set(g.x.c0, Bls12_377_Fq::G2X0); fe_set(g.x.c1, Bls12_377_Fq::G2X1);
+    fe_set(g.y.c0, Bls12_377_Fq::G2Y0); fe_set(g.y.c1, Bls12_377_Fq::G2Y1);
+  }
+};
 
 // Synthetic input generator in the shape of the reference harness (P1A yrrid/src/util.rs:15-28,
 // 6block/src/util.rs:15-29): `distinct` subgroup points P_j = (h0 + j*h1) * G, batch-normalised to affine
@@ -124,62 +170,64 @@ inline uint64_t splitmix64(uint64_t& s) {
   return z ^ (z >> 31);
 }
 
-template <class F>
-inline void xyzz_mul_u64x4(Xyzz& r, const Affine& g, const uint64_t k[4], const Modulus<F>& md) {
-  xyzz_set_inf<F>(r);
+template <class E>
+inline void xyzz_mul_u64x4(XyzzT<typename E::T>& r, const AffineT<typename E::T>& g, const uint64_t k[4], const typename E::Md& md) {
+  xyzz_set_inf<E>(r);
   for (int bit = 255; bit >= 0; bit--) {
-    if (!xyzz_is_inf<F>(r)) xyzz_dbl<F>(r, md);
-    if ((k[bit >> 6] >> (bit & 63)) & 1) xyzz_madd<F>(r, g, false, false, md);
+    if (!xyzz_is_inf<E>(r)) xyzz_dbl<E>(r, md);
+    if ((k[bit >> 6] >> (bit & 63)) & 1) xyzz_madd<E>(r, g, false, false, md);
   }
 }
 
-template <class F>
+template <class C>
 inline void generate_points(uint64_t seed, size_t distinct, size_t npoints, uint8_t* out, size_t stride) {
-  Modulus<F> md;
+  using E = typename C::E;
+  using El = typename E::T;
+  typename E::Md md;
   if (distinct > npoints) distinct = npoints;
   if (distinct == 0) return;
-  Affine g;
-  fe_set(g.x, F::G1X);
-  fe_set(g.y, F::G1Y);
+  AffineT<El> g;
+  C::generator(g);
   uint64_t st = seed, h0[4], h1[4];
   for (int i = 0; i < 4; i++) h0[i] = splitmix64(st);
   for (int i = 0; i < 4; i++) h1[i] = splitmix64(st);
   h0[3] &= 0x03ffffffffffffffull;  // 250-bit multipliers: below both group orders
   h1[3] &= 0x03ffffffffffffffull;
   h1[0] |= 1;
-  Xyzz acc, step;
-  xyzz_mul_u64x4<F>(acc, g, h0, md);
-  xyzz_mul_u64x4<F>(step, g, h1, md);
-  Xyzz* pts = new Xyzz[distinct];
-  Fe* prefix = new Fe[distinct];
-  Fe run;
-  fe_set(run, F::ONE);
+  XyzzT<El> acc, step;
+  xyzz_mul_u64x4<E>(acc, g, h0, md);
+  xyzz_mul_u64x4<E>(step, g, h1, md);
+  XyzzT<El>* pts = new XyzzT<El>[distinct];
+  El* prefix = new El[distinct];
+  El run;
+  E::set_one(run);
   for (size_t j = 0; j < distinct; j++) {
-    if (xyzz_is_inf<F>(acc)) xyzz_add<F>(acc, step, md);  // (measure-zero) skip the identity
+    if (xyzz_is_inf<E>(acc)) xyzz_add<E>(acc, step, md);  // (measure-zero) skip the identity
     pts[j] = acc;
     prefix[j] = run;                       // product of zz*zzz of all earlier points
-    Fe t;
-    fe_mul<F>(t, acc.zz, acc.zzz, md);
-    fe_mul<F>(run, run, t, md);
-    xyzz_add<F>(acc, step, md);
+    El t;
+    E::mul(t, acc.zz, acc.zzz, md);
+    E::mul(run, run, t, md);
+    xyzz_add<E>(acc, step, md);
   }
-  Fe inv;
-  fe_inv<F>(inv, run, md);
+  El inv;
+  el_inv(inv, run, md, (E*)nullptr);
+  constexpr int CB = E::WORDS * 4;
   for (size_t j = distinct; j-- > 0;) {
-    Fe t, ti, zzi, zzzi, x, y;
-    fe_mul<F>(ti, inv, prefix[j], md);     // (zz_j*zzz_j)^-1
-    fe_mul<F>(t, pts[j].zz, pts[j].zzz, md);
-    fe_mul<F>(inv, inv, t, md);
-    fe_mul<F>(zzi, ti, pts[j].zzz, md);
-    fe_mul<F>(zzzi, ti, pts[j].zz, md);
-    fe_mul<F>(x, pts[j].x, zzi, md);
-    fe_mul<F>(y, pts[j].y, zzzi, md);
-    uint32_t w[24];
-    fe_to_abi<F>(w, x, md);
-    fe_to_abi<F>(w + 12, y, md);
+    El t, ti, zzi, zzzi, x, y;
+    E::mul(ti, inv, prefix[j], md);        // (zz_j*zzz_j)^-1
+    E::mul(t, pts[j].zz, pts[j].zzz, md);
+    E::mul(inv, inv, t, md);
+    E::mul(zzi, ti, pts[j].zzz, md);
+    E::mul(zzzi, ti, pts[j].zz, md);
+    E::mul(x, pts[j].x, zzi, md);
+    E::mul(y, pts[j].y, zzzi, md);
+    uint32_t w[2 * E::WORDS];
+    E::to_abi(w, x, md);
+    E::to_abi(w + E::WORDS, y, md);
     uint8_t* o = out + j * stride;
     memset(o, 0, stride);
-    memcpy(o, w, 96);
+    memcpy(o, w, 2 * CB);
   }
   delete[] pts;
   delete[] prefix;

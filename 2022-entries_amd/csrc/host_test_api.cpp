@@ -19,6 +19,7 @@ static void msm_check_fail(const char* file, int line, const char* cond) {
 
 using namespace msm;
 
+// ---- base-field primitives (curve ids 0/1 select the modulus) ------------------------------------------------
 template <class F>
 static void t_fe_mul(const uint8_t* a, const uint8_t* b, uint8_t* out) {
   Modulus<F> md;
@@ -45,15 +46,42 @@ static void t_fe_sqr(const uint8_t* a, uint8_t* out) {
   memcpy(out, wo, 48);
 }
 
-// worst-case limbs for the column bounds: every limb 2^30 - 1 (the largest a multiply may see); only the checker matters
+// worst-case limbs for the column bounds: every limb at the largest value a multiply may see; only the checker matters
 template <class F>
-static void t_fe_extreme(int /*unused*/) {
+static void t_fe_extreme(int) {
   Modulus<F> md;
   Fe x, z;
   for (int i = 0; i < NL - 1; i++) x.v[i] = (1u << 30) - 1;
   x.v[NL - 1] = F::P[NL - 1] * 16;  // keeps the VALUE below 32p while every other limb sits at its bound
   fe_mul<F>(z, x, x, md);
   fe_sqr<F>(z, x, md);
+  Fe y;
+  for (int i = 0; i < NL - 1; i++) y.v[i] = (1u << 29) - 1;
+  y.v[NL - 1] = F::P[NL - 1] * 8;
+  fe_mul2<F>(z, y, y, y, y, md);
+}
+
+// k * a for small k through lazy limbs, then the weak reduction: out = canonical(k * a)
+template <class F>
+static void t_fe_weak_reduce(const uint8_t* a, int k, uint8_t* out) {
+  Modulus<F> md;
+  Fe x, z;
+  uint32_t wa[12], wo[12];
+  memcpy(wa, a, 48);
+  fe_from_abi<F>(x, wa, md);
+  fe_reduce<F>(x);
+  // k = k1 * k2 (k1 <= 7, k2 <= 4) through lazy limbs: multiply, parallel carry, multiply again -> limbs < 2^31
+  const int k1 = k > 7 ? 7 : k, k2 = k / k1;
+  for (int i = 0; i < NL; i++) z.v[i] = x.v[i] * (uint32_t)k1;
+  fe_carry(z);
+  for (int i = 0; i < NL; i++) z.v[i] *= (uint32_t)k2;
+  fe_weak_reduce<F>(z);
+  Fe three_p;  // result must be < 3p
+  for (int i = 0; i < NL; i++) three_p.v[i] = F::P[i] * 3;
+  fe_normalize(three_p);
+  MSM_CHECK(!fe_geq(z, three_p.v));
+  fe_to_abi<F>(wo, z, md);
+  memcpy(out, wo, 48);
 }
 
 template <class F>
@@ -79,70 +107,110 @@ static void t_fe_inv(const uint8_t* a, uint8_t* out) {
   memcpy(out, wo, 48);
 }
 
+// ---- coordinate-field and curve level (curve ids 0/1/2 = 377 G1, 381 G1, 377 G2) -----------------------------
+template <class C>
+static void t_el_mul(const uint8_t* a, const uint8_t* b, uint8_t* out) {
+  using E = typename C::E;
+  typename E::Md md;
+  typename E::T x, y, z;
+  uint32_t wa[E::WORDS], wb[E::WORDS], wo[E::WORDS];
+  memcpy(wa, a, 4 * E::WORDS);
+  memcpy(wb, b, 4 * E::WORDS);
+  E::from_abi(x, wa, md);
+  E::from_abi(y, wb, md);
+  E::mul(z, x, y, md);
+  E::to_abi(wo, z, md);
+  memcpy(out, wo, 4 * E::WORDS);
+}
+
+template <class C>
+static void t_el_inv(const uint8_t* a, uint8_t* out) {
+  using E = typename C::E;
+  typename E::Md md;
+  typename E::T x, z;
+  uint32_t wa[E::WORDS], wo[E::WORDS];
+  memcpy(wa, a, 4 * E::WORDS);
+  E::from_abi(x, wa, md);
+  el_inv(z, x, md, (E*)nullptr);
+  E::to_abi(wo, z, md);
+  memcpy(out, wo, 4 * E::WORDS);
+}
+
 // acc = inf; for each i: acc += (+/-) points[i] (mixed add); out = normalised projective.
-template <class F>
-static void t_madd_chain(const uint8_t* pts, size_t stride, const uint8_t* neg, size_t n, uint8_t* out144) {
-  Modulus<F> md;
-  Xyzz acc;
-  xyzz_set_inf<F>(acc);
+template <class C>
+static void t_madd_chain(const uint8_t* pts, size_t stride, const uint8_t* neg, size_t n, uint8_t* out) {
+  using E = typename C::E;
+  typename E::Md md;
+  XyzzT<typename E::T> acc;
+  xyzz_set_inf<E>(acc);
   for (size_t i = 0; i < n; i++) {
-    Affine p;
-    if (affine_from_abi<F>(p, pts + i * stride, md)) continue;
-    xyzz_madd<F>(acc, p, neg[i] != 0, false, md);
+    AffineT<typename E::T> p;
+    if (affine_from_abi<E>(p, pts + i * stride, md)) continue;
+    xyzz_madd<E>(acc, p, neg[i] != 0, false, md);
   }
-  xyzz_to_projective_abi<F>(out144, acc, md);
+  xyzz_to_projective_abi<E>(out, acc, md);
 }
 
 // out = (chain over first na points) + (chain over the remaining nb points), through the full XYZZ add.
-template <class F>
-static void t_add_chains(const uint8_t* pts, size_t stride, size_t na, size_t nb, uint8_t* out144) {
-  Modulus<F> md;
-  Xyzz a, b;
-  xyzz_set_inf<F>(a);
-  xyzz_set_inf<F>(b);
+template <class C>
+static void t_add_chains(const uint8_t* pts, size_t stride, size_t na, size_t nb, uint8_t* out) {
+  using E = typename C::E;
+  typename E::Md md;
+  XyzzT<typename E::T> a, b;
+  xyzz_set_inf<E>(a);
+  xyzz_set_inf<E>(b);
   for (size_t i = 0; i < na + nb; i++) {
-    Affine p;
-    if (affine_from_abi<F>(p, pts + i * stride, md)) continue;
-    xyzz_madd<F>(i < na ? a : b, p, false, false, md);
+    AffineT<typename E::T> p;
+    if (affine_from_abi<E>(p, pts + i * stride, md)) continue;
+    xyzz_madd<E>(i < na ? a : b, p, false, false, md);
   }
-  xyzz_add<F>(a, b, md);
-  xyzz_to_projective_abi<F>(out144, a, md);
+  xyzz_add<E>(a, b, md);
+  xyzz_to_projective_abi<E>(out, a, md);
 }
 
 // sum k_i P_i by per-point double-and-add (XYZZ dbl + XYZZ add), then one running total.
-template <class F>
-static void t_msm_naive(const uint8_t* pts, size_t stride, const uint8_t* scalars, size_t n, uint8_t* out144) {
-  Modulus<F> md;
-  Xyzz total;
-  xyzz_set_inf<F>(total);
+template <class C>
+static void t_msm_naive(const uint8_t* pts, size_t stride, const uint8_t* scalars, size_t n, uint8_t* out) {
+  using E = typename C::E;
+  typename E::Md md;
+  XyzzT<typename E::T> total;
+  xyzz_set_inf<E>(total);
   for (size_t i = 0; i < n; i++) {
-    Affine p;
-    if (affine_from_abi<F>(p, pts + i * stride, md)) continue;
+    AffineT<typename E::T> p;
+    if (affine_from_abi<E>(p, pts + i * stride, md)) continue;
     const uint8_t* k = scalars + 32 * i;
-    Xyzz r;
-    xyzz_set_inf<F>(r);
+    XyzzT<typename E::T> r;
+    xyzz_set_inf<E>(r);
     for (int bit = 255; bit >= 0; bit--) {
-      if (!xyzz_is_inf<F>(r)) xyzz_dbl<F>(r, md);
-      if ((k[bit >> 3] >> (bit & 7)) & 1) xyzz_madd<F>(r, p, false, false, md);
+      if (!xyzz_is_inf<E>(r)) xyzz_dbl<E>(r, md);
+      if ((k[bit >> 3] >> (bit & 7)) & 1) xyzz_madd<E>(r, p, false, false, md);
     }
-    xyzz_add<F>(total, r, md);
+    xyzz_add<E>(total, r, md);
   }
-  xyzz_to_projective_abi<F>(out144, total, md);
+  xyzz_to_projective_abi<E>(out, total, md);
 }
 
 // projective (Jacobian, any Z) -> normalised projective, through XYZZ.
-template <class F>
-static void t_normalize(const uint8_t* in144, uint8_t* out144) {
-  Modulus<F> md;
-  Xyzz a;
-  xyzz_from_projective_abi<F>(a, in144, md);
-  xyzz_to_projective_abi<F>(out144, a, md);
+template <class C>
+static void t_normalize(const uint8_t* in, uint8_t* out) {
+  using E = typename C::E;
+  typename E::Md md;
+  XyzzT<typename E::T> a;
+  xyzz_from_projective_abi<E>(a, in, md);
+  xyzz_to_projective_abi<E>(out, a, md);
 }
 
-#define DISPATCH(curve, fn, ...)                          \
+#define DISPATCH_F(curve, fn, ...)                        \
   switch (curve) {                                        \
     case 0: fn<Bls12_377_Fq>(__VA_ARGS__); return 0;      \
     case 1: fn<Bls12_381_Fq>(__VA_ARGS__); return 0;      \
+    default: return -1;                                   \
+  }
+#define DISPATCH_C(curve, fn, ...)                        \
+  switch (curve) {                                        \
+    case 0: fn<Bls12_377_G1>(__VA_ARGS__); return 0;      \
+    case 1: fn<Bls12_381_G1>(__VA_ARGS__); return 0;      \
+    case 2: fn<Bls12_377_G2>(__VA_ARGS__); return 0;      \
     default: return -1;                                   \
   }
 
@@ -150,13 +218,16 @@ extern "C" {
 long ht_check_failures(void) { return g_check_failures; }
 const char* ht_first_failure(void) { return g_first_failure; }
 void ht_reset_checks(void) { g_check_failures = 0; g_first_failure[0] = 0; }
-int ht_fe_mul(int curve, const uint8_t* a, const uint8_t* b, uint8_t* out) { DISPATCH(curve, t_fe_mul, a, b, out) }
-int ht_fe_sqr(int curve, const uint8_t* a, uint8_t* out) { DISPATCH(curve, t_fe_sqr, a, out) }
-int ht_fe_extreme(int curve) { DISPATCH(curve, t_fe_extreme, 0) }
-int ht_fe_roundtrip(int curve, const uint8_t* a, uint8_t* out) { DISPATCH(curve, t_fe_roundtrip, a, out) }
-int ht_fe_inv(int curve, const uint8_t* a, uint8_t* out) { DISPATCH(curve, t_fe_inv, a, out) }
-int ht_madd_chain(int curve, const uint8_t* pts, size_t stride, const uint8_t* neg, size_t n, uint8_t* out) { DISPATCH(curve, t_madd_chain, pts, stride, neg, n, out) }
-int ht_add_chains(int curve, const uint8_t* pts, size_t stride, size_t na, size_t nb, uint8_t* out) { DISPATCH(curve, t_add_chains, pts, stride, na, nb, out) }
-int ht_msm_naive(int curve, const uint8_t* pts, size_t stride, const uint8_t* scalars, size_t n, uint8_t* out) { DISPATCH(curve, t_msm_naive, pts, stride, scalars, n, out) }
-int ht_normalize(int curve, const uint8_t* in, uint8_t* out) { DISPATCH(curve, t_normalize, in, out) }
+int ht_fe_mul(int curve, const uint8_t* a, const uint8_t* b, uint8_t* out) { DISPATCH_F(curve, t_fe_mul, a, b, out) }
+int ht_fe_sqr(int curve, const uint8_t* a, uint8_t* out) { DISPATCH_F(curve, t_fe_sqr, a, out) }
+int ht_fe_extreme(int curve) { DISPATCH_F(curve, t_fe_extreme, 0) }
+int ht_fe_weak_reduce(int curve, const uint8_t* a, int k, uint8_t* out) { DISPATCH_F(curve, t_fe_weak_reduce, a, k, out) }
+int ht_fe_roundtrip(int curve, const uint8_t* a, uint8_t* out) { DISPATCH_F(curve, t_fe_roundtrip, a, out) }
+int ht_fe_inv(int curve, const uint8_t* a, uint8_t* out) { DISPATCH_F(curve, t_fe_inv, a, out) }
+int ht_el_mul(int curve, const uint8_t* a, const uint8_t* b, uint8_t* out) { DISPATCH_C(curve, t_el_mul, a, b, out) }
+int ht_el_inv(int curve, const uint8_t* a, uint8_t* out) { DISPATCH_C(curve, t_el_inv, a, out) }
+int ht_madd_chain(int curve, const uint8_t* pts, size_t stride, const uint8_t* neg, size_t n, uint8_t* out) { DISPATCH_C(curve, t_madd_chain, pts, stride, neg, n, out) }
+int ht_add_chains(int curve, const uint8_t* pts, size_t stride, size_t na, size_t nb, uint8_t* out) { DISPATCH_C(curve, t_add_chains, pts, stride, na, nb, out) }
+int ht_msm_naive(int curve, const uint8_t* pts, size_t stride, const uint8_t* scalars, size_t n, uint8_t* out) { DISPATCH_C(curve, t_msm_naive, pts, stride, scalars, n, out) }
+int ht_normalize(int curve, const uint8_t* in, uint8_t* out) { DISPATCH_C(curve, t_normalize, in, out) }
 }

@@ -1,0 +1,28 @@
+// launch.hpp -- host-callable launchers of the per-curve kernels.  Declared here, defined in launch_impl.cuh and
+// explicitly instantiated once per curve in kernels_<curve>.hip, so the three curve instantiations (each minutes of
+// hipcc time: every field multiply is fully unrolled) compile in parallel and the engine TU stays small.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "host_curve.hpp"
+#include "msm_types.cuh"
+
+namespace msm {
+
+template <class E>
+struct Launch {
+  using El = typename E::T;
+  static hipError_t convert_bases(const uint8_t* in, size_t stride, uint32_t n, AffineDevT<El>* out, uint8_t* inf, hipStream_t st);
+  static hipError_t accumulate(const uint32_t* keys, const uint32_t* vals, uint32_t n_entries, uint32_t K, uint32_t sentinel,
+                               const AffineDevT<El>* bases, SegOutT<El> out, uint32_t nlanes, hipStream_t st);
+  static hipError_t segreduce(const XyzzDevT<El>* in_slots, const uint32_t* in_keys, uint32_t n_in, uint32_t K, SegOutT<El> out,
+                              uint32_t nlanes, hipStream_t st);
+  static hipError_t bucket_reduce(bool first, const XyzzDevT<El>* in_a, const XyzzDevT<El>* in_x, uint32_t n_per_win, uint32_t logL,
+                                  uint32_t chunks, uint32_t windows, XyzzDevT<El>* out_a, XyzzDevT<El>* out_x, hipStream_t st);
+};
+
+extern template struct Launch<Bls12_377_G1::E>;
+extern template struct Launch<Bls12_381_G1::E>;
+extern template struct Launch<Bls12_377_G2::E>;
+
+}  // namespace msm

@@ -21,7 +21,8 @@
 
 #include "../../include/mi355_msm.h"
 #include "host_curve.hpp"
-#include "msm_kernels.cuh"
+#include "launch.hpp"
+#include "digits.cuh"
 
 namespace {
 
@@ -107,10 +108,6 @@ int choose_window_bits(size_t n) {
   return best;
 }
 
-template <class F> struct ScalarFieldOf;
-template <> struct ScalarFieldOf<Bls12_377_Fq> { using type = Bls12_377_Fr; };
-template <> struct ScalarFieldOf<Bls12_381_Fq> { using type = Bls12_381_Fr; };
-
 struct Plan {
   uint32_t c, windows, half, sentinel, keybits;
   uint64_t entries;     // windows * n
@@ -162,64 +159,56 @@ namespace {
 
 void ensure_device(mi355_msm_ctx* ctx) { HIP_OK(hipSetDevice(ctx->device)); }
 
-template <class F>
+// Run `fn.template operator()<Curve>()` for the curve id.
+template <class Fn>
+void with_curve(int curve, Fn&& fn) {
+  switch (curve) {
+    case MI355_BLS12_377_G1: fn.template operator()<Bls12_377_G1>(); break;
+    case MI355_BLS12_381_G1: fn.template operator()<Bls12_381_G1>(); break;
+    case MI355_BLS12_377_G2: fn.template operator()<Bls12_377_G2>(); break;
+    default: bad_arg("unknown curve id %d", curve);
+  }
+}
+bool known_curve(int c) { return c == MI355_BLS12_377_G1 || c == MI355_BLS12_381_G1 || c == MI355_BLS12_377_G2; }
+size_t coord_bytes(int curve) { return curve == MI355_BLS12_377_G2 ? 96 : 48; }
+
+template <class C>
 void convert_bases(mi355_msm_ctx* ctx, const uint8_t* d_raw, size_t n, size_t stride, hipStream_t st) {
-  ctx->bases.reserve(n * sizeof(AffineDev));
+  using E = typename C::E;
+  using AD = AffineDevT<typename E::T>;
+  ctx->bases.reserve(n * sizeof(AD));
   ctx->inf.reserve(n);
-  hipLaunchKernelGGL((k_convert_bases<F>), dim3(ceil_div(n, 256)), dim3(256), 0, st, d_raw, stride, (uint32_t)n,
-                     ctx->bases.as<AffineDev>(), ctx->inf.as<uint8_t>());
-  HIP_OK(hipGetLastError());
+  HIP_OK(Launch<E>::convert_bases(d_raw, stride, (uint32_t)n, ctx->bases.as<AD>(), ctx->inf.as<uint8_t>(), st));
 }
 
 void set_bases_device(mi355_msm_ctx* ctx, const void* d_affine, size_t n, size_t stride) {
   ensure_device(ctx);
-  if (stride < 97 || (stride & 3)) bad_arg("affine stride %zu is not a 4-byte multiple >= 97", stride);
+  const size_t min_stride = 2 * coord_bytes(ctx->curve) + 1;
+  if (stride < min_stride || (stride & 3)) bad_arg("affine stride %zu is not a 4-byte multiple >= %zu", stride, min_stride);
   if (n >= (1ull << 31)) bad_arg("npoints %zu exceeds 2^31-1", n);
   if (n) {
-    if (ctx->curve == MI355_BLS12_377_G1)
-      convert_bases<Bls12_377_Fq>(ctx, (const uint8_t*)d_affine, n, stride, ctx->own_stream);
-    else
-      convert_bases<Bls12_381_Fq>(ctx, (const uint8_t*)d_affine, n, stride, ctx->own_stream);
+    with_curve(ctx->curve, [&]<class C>() { convert_bases<C>(ctx, (const uint8_t*)d_affine, n, stride, ctx->own_stream); });
     HIP_OK(hipStreamSynchronize(ctx->own_stream));
   }
   ctx->nbases = n;
 }
 
-template <class F>
-void launch_accumulate(const Plan& p, const uint32_t* keys, const uint32_t* vals, const AffineDev* bases, SegOut out,
-                       hipStream_t st) {
-  hipLaunchKernelGGL((k_accumulate<F>), dim3(ceil_div(p.nlanes, 256)), dim3(256), 0, st, keys, vals, (uint32_t)p.entries,
-                     p.K, p.sentinel, bases, out, p.nlanes);
-  HIP_OK(hipGetLastError());
-}
-
-template <class F>
-void launch_segreduce(const XyzzDev* in_slots, const uint32_t* in_keys, uint32_t n_in, uint32_t K, SegOut out,
-                      uint32_t nlanes, hipStream_t st) {
-  hipLaunchKernelGGL((k_segreduce<F>), dim3(ceil_div(nlanes, 256)), dim3(256), 0, st, in_slots, in_keys, n_in, K, out, nlanes);
-  HIP_OK(hipGetLastError());
-}
-
-template <class F>
-void launch_bucket_reduce(bool first, const XyzzDev* in_a, const XyzzDev* in_x, uint32_t n_per_win, uint32_t logL,
-                          uint32_t chunks, uint32_t windows, XyzzDev* out_a, XyzzDev* out_x, hipStream_t st) {
-  dim3 grid(ceil_div((uint64_t)windows * chunks, 256));
-  if (first)
-    hipLaunchKernelGGL((k_bucket_reduce<F, true>), grid, dim3(256), 0, st, in_a, in_x, n_per_win, logL, chunks, windows, out_a, out_x);
-  else
-    hipLaunchKernelGGL((k_bucket_reduce<F, false>), grid, dim3(256), 0, st, in_a, in_x, n_per_win, logL, chunks, windows, out_a, out_x);
-  HIP_OK(hipGetLastError());
-}
-
 // One chunk of one batch: device scalars [0, n) against bases [base0, base0 + n).  Leaves the folded chunk sum in `out`.
-template <class F>
-void run_chunk(mi355_msm_ctx* ctx, const uint32_t* d_scalars, size_t base0, size_t n, hipStream_t st, Xyzz& out) {
+template <class C>
+void run_chunk(mi355_msm_ctx* ctx, const uint32_t* d_scalars, size_t base0, size_t n, hipStream_t st,
+               XyzzT<typename C::E::T>& out) {
+  using E = typename C::E;
+  using El = typename E::T;
+  using XyzzDev = XyzzDevT<El>;
+  using AffineDev = AffineDevT<El>;
+  using SegOut = SegOutT<El>;
+  using Xyzz = XyzzT<El>;
   const Plan p = ctx->plan(n);
   if (p.entries >= (1ull << 32)) bad_arg("chunk of %zu pairs needs %llu sort entries (>= 2^32)", n, (unsigned long long)p.entries);
-  const size_t E = p.entries;
+  const size_t NE = p.entries;
   for (int i = 0; i < 2; i++) {
-    ctx->keys[i].reserve(E * 4);
-    ctx->vals[i].reserve(E * 4);
+    ctx->keys[i].reserve(NE * 4);
+    ctx->vals[i].reserve(NE * 4);
   }
   const size_t nbuckets = (size_t)p.windows * p.half;
   ctx->buckets.reserve(nbuckets * sizeof(XyzzDev));
@@ -242,14 +231,14 @@ void run_chunk(mi355_msm_ctx* ctx, const uint32_t* d_scalars, size_t base0, size
   rocprim::double_buffer<uint32_t> kbuf(ctx->keys[0].as<uint32_t>(), ctx->keys[1].as<uint32_t>());
   rocprim::double_buffer<uint32_t> vbuf(ctx->vals[0].as<uint32_t>(), ctx->vals[1].as<uint32_t>());
   size_t tmp_bytes = 0;
-  HIP_OK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, kbuf, vbuf, E, 0, p.keybits, st));
+  HIP_OK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, kbuf, vbuf, NE, 0, p.keybits, st));
   ctx->sort_tmp.reserve(tmp_bytes ? tmp_bytes : 16);
 
   const AffineDev* bases = ctx->bases.as<AffineDev>() + base0;
   const uint8_t* inf = ctx->inf.as<uint8_t>() + base0;
 
   HIP_OK(hipEventRecord(ctx->ev[0], st));
-  using FR = typename ScalarFieldOf<F>::type;
+  using FR = typename C::FR;
   if (ctx->opt_scalars_montgomery)
     hipLaunchKernelGGL((k_digits<FR, true>), dim3(ceil_div(n, 256)), dim3(256), 0, st, d_scalars, inf, (uint32_t)n, p.c,
                        p.windows, kbuf.current(), vbuf.current());
@@ -258,12 +247,12 @@ void run_chunk(mi355_msm_ctx* ctx, const uint32_t* d_scalars, size_t base0, size
                        p.windows, kbuf.current(), vbuf.current());
   HIP_OK(hipGetLastError());
   HIP_OK(hipEventRecord(ctx->ev[1], st));
-  HIP_OK(rocprim::radix_sort_pairs(ctx->sort_tmp.p, tmp_bytes, kbuf, vbuf, E, 0, p.keybits, st));
+  HIP_OK(rocprim::radix_sort_pairs(ctx->sort_tmp.p, tmp_bytes, kbuf, vbuf, NE, 0, p.keybits, st));
   HIP_OK(hipMemsetAsync(ctx->buckets.p, 0, nbuckets * sizeof(XyzzDev), st));
   HIP_OK(hipEventRecord(ctx->ev[2], st));
 
   SegOut so{ctx->buckets.as<XyzzDev>(), ctx->slots[0].as<XyzzDev>(), ctx->slot_keys[0].as<uint32_t>()};
-  launch_accumulate<F>(p, kbuf.current(), vbuf.current(), bases, so, st);
+  HIP_OK(Launch<E>::accumulate(kbuf.current(), vbuf.current(), (uint32_t)p.entries, p.K, p.sentinel, bases, so, p.nlanes, st));
   HIP_OK(hipEventRecord(ctx->ev[3], st));
 
   // merge the run fragments that crossed lane boundaries
@@ -274,7 +263,7 @@ void run_chunk(mi355_msm_ctx* ctx, const uint32_t* d_scalars, size_t base0, size
       uint32_t nl = ceil_div(n_in, p.segK);
       if (nl > 1 && 2 * (uint64_t)nl >= n_in) bad_arg("fragment merge would not shrink (%u slots, fan-in %u)", n_in, p.segK);
       SegOut o{ctx->buckets.as<XyzzDev>(), ctx->slots[cur ^ 1].as<XyzzDev>(), ctx->slot_keys[cur ^ 1].as<uint32_t>()};
-      launch_segreduce<F>(ctx->slots[cur].as<XyzzDev>(), ctx->slot_keys[cur].as<uint32_t>(), n_in, p.segK, o, nl, st);
+      HIP_OK(Launch<E>::segreduce(ctx->slots[cur].as<XyzzDev>(), ctx->slot_keys[cur].as<uint32_t>(), n_in, p.segK, o, nl, st));
       if (nl == 1) break;
       n_in = 2 * nl;
       cur ^= 1;
@@ -285,14 +274,14 @@ void run_chunk(mi355_msm_ctx* ctx, const uint32_t* d_scalars, size_t base0, size
   // buckets -> one point per window
   uint32_t n_per_win = p.half, logL = p.logL0, chunks = p.T0;
   int rb = 0;
-  launch_bucket_reduce<F>(true, nullptr, ctx->buckets.as<XyzzDev>(), n_per_win, logL, chunks, p.windows,
-                          ctx->red_a[0].as<XyzzDev>(), ctx->red_x[0].as<XyzzDev>(), st);
+  HIP_OK(Launch<E>::bucket_reduce(true, nullptr, ctx->buckets.as<XyzzDev>(), n_per_win, logL, chunks, p.windows,
+                                  ctx->red_a[0].as<XyzzDev>(), ctx->red_x[0].as<XyzzDev>(), st));
   while (chunks > 1) {
     n_per_win = chunks;
     logL = p.logL;
     chunks = ceil_div(n_per_win, 1u << logL);
-    launch_bucket_reduce<F>(false, ctx->red_a[rb].as<XyzzDev>(), ctx->red_x[rb].as<XyzzDev>(), n_per_win, logL, chunks,
-                            p.windows, ctx->red_a[rb ^ 1].as<XyzzDev>(), ctx->red_x[rb ^ 1].as<XyzzDev>(), st);
+    HIP_OK(Launch<E>::bucket_reduce(false, ctx->red_a[rb].as<XyzzDev>(), ctx->red_x[rb].as<XyzzDev>(), n_per_win, logL, chunks,
+                                    p.windows, ctx->red_a[rb ^ 1].as<XyzzDev>(), ctx->red_x[rb ^ 1].as<XyzzDev>(), st));
     rb ^= 1;
   }
   HIP_OK(hipEventRecord(ctx->ev[5], st));
@@ -300,11 +289,11 @@ void run_chunk(mi355_msm_ctx* ctx, const uint32_t* d_scalars, size_t base0, size
   HIP_OK(hipEventRecord(ctx->ev[6], st));
   HIP_OK(hipStreamSynchronize(st));
 
-  Modulus<F> md;
+  typename E::Md md;
   std::vector<Xyzz> sums(p.windows);
   const XyzzDev* hs = reinterpret_cast<const XyzzDev*>(ctx->pinned);
   for (uint32_t w = 0; w < p.windows; w++) sums[w] = hs[w].p;
-  fold_windows<F>(out, sums.data(), (int)p.windows, (int)p.c, md);
+  fold_windows<E>(out, sums.data(), (int)p.windows, (int)p.c, md);
 
   float ms = 0;
   for (int s = 0; s < 5; s++) {
@@ -315,26 +304,29 @@ void run_chunk(mi355_msm_ctx* ctx, const uint32_t* d_scalars, size_t base0, size
   ctx->last_ms[MI355_T_TOTAL] += ms;
   ctx->last_info[0] = p.c;
   ctx->last_info[1] = p.windows;
-  ctx->last_info[2] = E;
+  ctx->last_info[2] = NE;
   ctx->last_info[3] = p.K;
   ctx->last_info[4] += 1;
   ctx->last_info[5] = p.nlanes;
 }
 
-template <class F>
+template <class C>
 void run_device_t(mi355_msm_ctx* ctx, uint8_t* out, const uint32_t* d_scalars, size_t n, size_t batches, hipStream_t st) {
-  Modulus<F> md;
+  using E = typename C::E;
+  using Xyzz = XyzzT<typename E::T>;
+  typename E::Md md;
   const size_t max_chunk = ctx->opt_max_chunk ? (size_t)ctx->opt_max_chunk : ((size_t)1 << 26);
+  const size_t out_bytes = 3 * 4 * E::WORDS;
   for (size_t b = 0; b < batches; b++) {
     Xyzz total;
-    xyzz_set_inf<F>(total);
+    xyzz_set_inf<E>(total);
     for (size_t off = 0; off < n; off += max_chunk) {
       size_t cn = std::min(max_chunk, n - off);
       Xyzz part;
-      run_chunk<F>(ctx, d_scalars + (b * n + off) * 8, off, cn, st, part);
-      xyzz_add<F>(total, part, md);
+      run_chunk<C>(ctx, d_scalars + (b * n + off) * 8, off, cn, st, part);
+      xyzz_add<E>(total, part, md);
     }
-    xyzz_to_projective_abi<F>(out + b * 144, total, md);
+    xyzz_to_projective_abi<E>(out + b * out_bytes, total, md);
   }
 }
 
@@ -345,23 +337,21 @@ void run_device(mi355_msm_ctx* ctx, void* out, const void* d_scalars, size_t n, 
   memset(ctx->last_ms, 0, sizeof ctx->last_ms);
   memset(ctx->last_info, 0, sizeof ctx->last_info);
   if (!st) st = ctx->own_stream;
-  if (ctx->curve == MI355_BLS12_377_G1)
-    run_device_t<Bls12_377_Fq>(ctx, (uint8_t*)out, (const uint32_t*)d_scalars, n, batches, st);
-  else
-    run_device_t<Bls12_381_Fq>(ctx, (uint8_t*)out, (const uint32_t*)d_scalars, n, batches, st);
+  with_curve(ctx->curve, [&]<class C>() { run_device_t<C>(ctx, (uint8_t*)out, (const uint32_t*)d_scalars, n, batches, st); });
 }
 
-template <class F>
+template <class C>
 void fold_t(uint8_t* out, const uint8_t* in, size_t count) {
-  Modulus<F> md;
-  Xyzz total;
-  xyzz_set_inf<F>(total);
+  using E = typename C::E;
+  typename E::Md md;
+  XyzzT<typename E::T> total;
+  xyzz_set_inf<E>(total);
   for (size_t i = 0; i < count; i++) {
-    Xyzz p;
-    xyzz_from_projective_abi<F>(p, in + 144 * i, md);
-    xyzz_add<F>(total, p, md);
+    XyzzT<typename E::T> p;
+    xyzz_from_projective_abi<E>(p, in + (size_t)3 * 4 * E::WORDS * i, md);
+    xyzz_add<E>(total, p, md);
   }
-  xyzz_to_projective_abi<F>(out, total, md);
+  xyzz_to_projective_abi<E>(out, total, md);
 }
 
 }  // namespace
@@ -372,7 +362,7 @@ RustError mi355_msm_create(mi355_msm_ctx** out, int curve, int device) {
   return guarded([&] {
     if (!out) bad_arg("null context out-pointer");
     *out = nullptr;
-    if (curve != MI355_BLS12_377_G1 && curve != MI355_BLS12_381_G1) bad_arg("unknown curve id %d", curve);
+    if (!known_curve(curve)) bad_arg("unknown curve id %d", curve);
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
     if (e != hipSuccess || count == 0)
@@ -506,25 +496,16 @@ RustError mi355_msm(int curve, void* out, const void* affine, size_t npoints, co
 RustError mi355_msm_fold(int curve, void* out, const void* projective, size_t count) {
   return guarded([&] {
     if (!out || (count && !projective)) bad_arg("null pointer");
-    if (curve == MI355_BLS12_377_G1)
-      fold_t<Bls12_377_Fq>((uint8_t*)out, (const uint8_t*)projective, count);
-    else if (curve == MI355_BLS12_381_G1)
-      fold_t<Bls12_381_Fq>((uint8_t*)out, (const uint8_t*)projective, count);
-    else
-      bad_arg("unknown curve id %d", curve);
+    with_curve(curve, [&]<class C>() { fold_t<C>((uint8_t*)out, (const uint8_t*)projective, count); });
   });
 }
 
 RustError mi355_msm_generate_points(int curve, uint64_t seed, size_t distinct, size_t npoints, void* out, size_t stride) {
   return guarded([&] {
     if (npoints && !out) bad_arg("null output pointer");
-    if (stride < 97) bad_arg("affine stride %zu too small", stride);
-    if (curve == MI355_BLS12_377_G1)
-      generate_points<Bls12_377_Fq>(seed, distinct, npoints, (uint8_t*)out, stride);
-    else if (curve == MI355_BLS12_381_G1)
-      generate_points<Bls12_381_Fq>(seed, distinct, npoints, (uint8_t*)out, stride);
-    else
-      bad_arg("unknown curve id %d", curve);
+    if (!known_curve(curve)) bad_arg("unknown curve id %d", curve);
+    if (stride < 2 * coord_bytes(curve) + 1) bad_arg("affine stride %zu too small", stride);
+    with_curve(curve, [&]<class C>() { generate_points<C>(seed, distinct, npoints, (uint8_t*)out, stride); });
   });
 }
 

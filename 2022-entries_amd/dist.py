@@ -11,7 +11,7 @@ from __future__ import annotations
 
 from typing import Callable, List, Optional, Tuple
 
-from .msm import PROJECTIVE_BYTES, fold_partials
+from .msm import fold_partials, projective_bytes
 
 
 def shard_bounds(n: int, world: int, rank: int) -> Tuple[int, int]:
@@ -22,20 +22,21 @@ def shard_bounds(n: int, world: int, rank: int) -> Tuple[int, int]:
 
 
 def all_gather_partials(partial: bytes, device=None, group=None) -> List[bytes]:
-    """All-gather one 144-byte projective image per rank (uint8 tensor; on ``device`` for the nccl backend)."""
+    """All-gather one projective image per rank (144 B for G1, 288 B for G2; uint8 tensor, on ``device`` for nccl)."""
     import torch
     import torch.distributed as dist
 
-    if len(partial) != PROJECTIVE_BYTES:
-        raise ValueError("partial must be a 144-byte projective image")
+    nb = len(partial)
+    if nb not in (144, 288):
+        raise ValueError("partial must be a 144-byte (G1) or 288-byte (G2) projective image")
     world = dist.get_world_size(group)
     t = torch.frombuffer(bytearray(partial), dtype=torch.uint8)
     if device is not None:
         t = t.to(device)
-    out = torch.empty(world * PROJECTIVE_BYTES, dtype=torch.uint8, device=t.device)
+    out = torch.empty(world * nb, dtype=torch.uint8, device=t.device)
     dist.all_gather_into_tensor(out, t, group=group)
     raw = out.cpu().numpy().tobytes()
-    return [raw[i * PROJECTIVE_BYTES:(i + 1) * PROJECTIVE_BYTES] for i in range(world)]
+    return [raw[i * nb:(i + 1) * nb] for i in range(world)]
 
 
 def sharded_msm(local_msm: Callable[[], bytes], curve="bls12_377_g1", device=None, group=None) -> bytes:

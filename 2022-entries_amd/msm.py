@@ -23,10 +23,21 @@ import ctypes
 import os
 from typing import List, Optional, Sequence
 
-CURVE_IDS = {"bls12_377_g1": 0, "bls12_381_g1": 1}
-AFFINE_STRIDE = 104
+CURVE_IDS = {"bls12_377_g1": 0, "bls12_381_g1": 1, "bls12_377_g2": 2}
+AFFINE_STRIDE = 104          # size_of::<G1Affine>()
 SCALAR_BYTES = 32
-PROJECTIVE_BYTES = 144
+PROJECTIVE_BYTES = 144       # size_of::<G1Projective>()
+_COORD_BYTES = {0: 48, 1: 48, 2: 96}   # G2 coordinates live in Fq2 (c0 | c1)
+
+
+def affine_stride(curve) -> int:
+    """size_of::<Affine>() for the curve: two coordinates + the infinity flag, padded to 8 (104 for G1, 200 for G2)."""
+    return 2 * _COORD_BYTES[_curve_id(curve)] + 8
+
+
+def projective_bytes(curve) -> int:
+    """size_of::<Projective>(): three coordinates (144 for G1, 288 for G2)."""
+    return 3 * _COORD_BYTES[_curve_id(curve)]
 T_NAMES = ("digits", "sort", "accumulate", "segreduce", "bucket_reduce", "host_fold", "total")
 
 _LIB = None
@@ -158,7 +169,8 @@ class MultiScalarMultContext:
         _check(self._lib.mi355_msm_create(ctypes.byref(self.context), self.curve, -1 if device is None else device))
         self.npoints = 0
 
-    def set_bases(self, points, stride: int = AFFINE_STRIDE) -> None:
+    def set_bases(self, points, stride: Optional[int] = None) -> None:
+        stride = affine_stride(self.curve) if stride is None else stride
         b = _Buf(points)
         if b.nbytes % stride:
             raise ValueError(f"points image of {b.nbytes} bytes is not a multiple of the {stride}-byte affine stride")
@@ -179,13 +191,14 @@ class MultiScalarMultContext:
             batches = count // n if count % n == 0 else None
         if batches is None:
             raise ValueError(f"{count} scalars is not a whole number of batches of {n} points")
-        out = ctypes.create_string_buffer(PROJECTIVE_BYTES * max(batches, 1))
+        pb = projective_bytes(self.curve)
+        out = ctypes.create_string_buffer(pb * max(batches, 1))
         if b.is_device:
             _check(self._lib.mi355_msm_run_device(self.context, out, b.ptr, n, batches, b.stream))
         else:
             _check(self._lib.mi355_msm_run(self.context, out, b.ptr, n, batches))
         raw = out.raw
-        return [raw[i * PROJECTIVE_BYTES:(i + 1) * PROJECTIVE_BYTES] for i in range(batches)]
+        return [raw[i * pb:(i + 1) * pb] for i in range(batches)]
 
     def set_option(self, key: str, value: int) -> None:
         _check(self._lib.mi355_msm_set_option(self.context, key.encode(), int(value)))
@@ -221,7 +234,7 @@ def multi_scalar_mult_init(points, curve="bls12_377_g1", device: Optional[int] =
 def multi_scalar_mult(ctx: MultiScalarMultContext, points, scalars) -> List[bytes]:
     """One 144-byte projective image per batch; ``points`` is only used for its length, as in the reference
     (``npoints = points.len()``, P1A 6block/src/lib.rs:92-101)."""
-    npoints = ctx.npoints if points is None else _Buf(points).nbytes // AFFINE_STRIDE
+    npoints = ctx.npoints if points is None else _Buf(points).nbytes // affine_stride(ctx.curve)
     if npoints != ctx.npoints:
         raise MsmError(-1, f"context was initialised with {ctx.npoints} points, called with {npoints}")
     return ctx.run(scalars, npoints)
@@ -229,17 +242,18 @@ def multi_scalar_mult(ctx: MultiScalarMultContext, points, scalars) -> List[byte
 
 def msm(bases, scalars, curve="bls12_377_g1") -> bytes:
     """Stateless ``msm(bases, scalars, n)``; chops to the shorter input like VariableBaseMSM::msm."""
-    nb = _Buf(bases).nbytes // AFFINE_STRIDE
+    stride = affine_stride(curve)
+    nb = _Buf(bases).nbytes // stride
     ns = _Buf(scalars).nbytes // SCALAR_BYTES
     n = min(nb, ns)
     ctx = MultiScalarMultContext(curve)
     try:
         pb, sb = _Buf(bases), _Buf(scalars)
         if pb.is_device or sb.is_device:
-            ctx.set_bases(bases[: n * AFFINE_STRIDE])
+            ctx.set_bases(bases[: n * stride])
             return ctx.run(scalars[: n * SCALAR_BYTES], n)[0]
-        out = ctypes.create_string_buffer(PROJECTIVE_BYTES)
-        _check(ctx._lib.mi355_msm(ctx.curve, out, pb.ptr, n, sb.ptr, AFFINE_STRIDE))
+        out = ctypes.create_string_buffer(projective_bytes(curve))
+        _check(ctx._lib.mi355_msm(ctx.curve, out, pb.ptr, n, sb.ptr, stride))
         return out.raw
     finally:
         ctx.close()
@@ -256,7 +270,7 @@ class VariableBaseMSM:
 
     def msm_checked(self, bases, scalars):
         """``Ok(point)`` as bytes, or ``Err(min_len)`` as an int when lengths differ."""
-        nb = _Buf(bases).nbytes // AFFINE_STRIDE
+        nb = _Buf(bases).nbytes // affine_stride(self.curve)
         ns = _Buf(scalars).nbytes // SCALAR_BYTES
         if nb != ns:
             return min(nb, ns)
@@ -266,23 +280,25 @@ class VariableBaseMSM:
 
 
 def fold_partials(partials: Sequence[bytes], curve="bls12_377_g1") -> bytes:
-    """Sum per-GPU partial results (144-B projective images) into one normalised image."""
+    """Sum per-GPU partial results (projective images: 144 B for G1, 288 B for G2) into one normalised image."""
     lib = load_library()
+    pb = projective_bytes(curve)
     blob = b"".join(bytes(p) for p in partials)
-    if len(blob) % PROJECTIVE_BYTES:
-        raise ValueError("partials must be 144-byte projective images")
-    out = ctypes.create_string_buffer(PROJECTIVE_BYTES)
+    if len(blob) % pb:
+        raise ValueError(f"partials must be {pb}-byte projective images")
+    out = ctypes.create_string_buffer(pb)
     buf = ctypes.create_string_buffer(blob, len(blob) if blob else 1)
-    _check(lib.mi355_msm_fold(_curve_id(curve), out, buf, len(blob) // PROJECTIVE_BYTES))
+    _check(lib.mi355_msm_fold(_curve_id(curve), out, buf, len(blob) // pb))
     return out.raw
 
 
 def generate_points(npoints: int, distinct: int = 1 << 15, seed: int = 0x5A5052495A45, curve="bls12_377_g1"):
     """Synthetic bases in the reference generator's shape (P1A yrrid/src/util.rs:15-28): ``distinct`` subgroup points
-    replicated by doubling up to ``npoints``; returns a NumPy uint8 array of shape (npoints, 104)."""
+    replicated by doubling up to ``npoints``; returns a NumPy uint8 array of shape (npoints, stride) (stride 104, G2: 200)."""
     import numpy as np
 
     lib = load_library()
-    out = np.zeros((npoints, AFFINE_STRIDE), dtype=np.uint8)
-    _check(lib.mi355_msm_generate_points(_curve_id(curve), seed, distinct, npoints, out.ctypes.data, AFFINE_STRIDE))
+    stride = affine_stride(curve)
+    out = np.zeros((npoints, stride), dtype=np.uint8)
+    _check(lib.mi355_msm_generate_points(_curve_id(curve), seed, distinct, npoints, out.ctypes.data, stride))
     return out

@@ -14,7 +14,7 @@
  *            then a 1-byte infinity flag; element stride is passed explicitly (104 B for G1).
  *            The flag byte is authoritative for infinity, not the coordinates.
  *   scalars  32 B each, 4 x u64 little-endian, plain integers (`BigInteger256`).
- *   results  arkworks `Projective` images (Jacobian X, Y, Z; 3 x 48 B Montgomery), written NORMALISED:
+ *   results  arkworks `Projective` images (Jacobian X, Y, Z; 3 x 48 B Montgomery; 3 x 96 B for G2), written NORMALISED:
  *            (x, y, 1), or (1, 1, 0) for the point at infinity -- so equal points are equal bytes.
  *
  * Errors: `RustError { int code; char *message; }` returned by value, exactly sppark's convention
@@ -45,7 +45,9 @@ typedef struct mi355_msm_ctx mi355_msm_ctx;
 
 enum {
   MI355_BLS12_377_G1 = 0, /* fq: ARKC bls12_377/src/fields/fq.rs:4, curve b = 1 */
-  MI355_BLS12_381_G1 = 1  /* fq: ARKC bls12_381/src/fields/fq.rs:4, curve b = 4 */
+  MI355_BLS12_381_G1 = 1, /* fq: ARKC bls12_381/src/fields/fq.rs:4, curve b = 4 */
+  MI355_BLS12_377_G2 = 2  /* coordinates in Fq2 = Fq[u]/(u^2+5) (ARKC bls12_377/src/fields/fq2.rs:13, curves/g2.rs:47-78):
+                             Affine images are 200 B (x.c0 x.c1 y.c0 y.c1, flag at byte 192), Projective images 288 B */
 };
 
 /* Stage indices of mi355_msm_last_timings(). */

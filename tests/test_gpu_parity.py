@@ -43,6 +43,7 @@ def test_native_library_is_the_one_running(ea, torch_cuda):
 
 
 def test_golden_vectors(ea, golden, torch_cuda):
+    assert {c["curve"] for c in golden} == {"bls12_377_g1", "bls12_381_g1", "bls12_377_g2"}
     for case in golden:
         bases, scalars = bytes.fromhex(case["bases"]), bytes.fromhex(case["scalars"])
         ctx = ea.multi_scalar_mult_init(bases, case["curve"])
@@ -172,6 +173,87 @@ def test_prefix_run_and_errors(ea, oracle, torch_cuda):
         ctx.run(np.zeros((n + 1, 32), dtype=np.uint8), npoints=n + 1)   # more points than uploaded bases
     with pytest.raises(ValueError):
         ctx.run(np.zeros((n + 1, 32), dtype=np.uint8))                  # not a whole number of batches
+    ctx.close()
+
+
+# ---- G2 (BASELINE.json configs[4]): Fq2 coordinates through the same kernels ------------------------------------
+
+def _oracle_g2(oracle, bases_np, scalars_np, n):
+    out = ctypes.create_string_buffer(288)
+    assert oracle.oracle_msm(2, bases_np.ctypes.data, 200, scalars_np.ctypes.data, n, out, 0) == 0
+    return out.raw
+
+
+@pytest.mark.parametrize("npow", [8, 12, 16])
+def test_g2_random_vs_oracle(ea, oracle, torch_cuda, npow):
+    n = 1 << npow
+    bases = ea.generate_points(n, distinct=min(n, 256), seed=npow, curve="bls12_377_g2")
+    assert bases.shape == (n, 200)
+    scalars = rand_scalars_np(0, 2 * n, seed=500 + npow)
+    ctx = ea.multi_scalar_mult_init(torch_cuda.from_numpy(bases).cuda(), "bls12_377_g2")
+    got = ea.multi_scalar_mult(ctx, None, torch_cuda.from_numpy(scalars).cuda())
+    assert len(got) == 2 and len(got[0]) == 288
+    for b in range(2):
+        assert got[b] == _oracle_g2(oracle, bases, np.ascontiguousarray(scalars[b * n:(b + 1) * n]), n), (npow, b)
+    ctx.close()
+
+
+def test_g2_edge_cases_and_stateless(ea, oracle, torch_cuda):
+    c = m.BLS12_377_G2
+    rng = random.Random(77)
+    for n in (0, 1, 2, 31, 33, 300):
+        pts = m.random_points(c, n, rng, max(1, n // 4)) if n else []
+        sc = m.random_scalars(c, n, rng)
+        if n > 4:
+            sc[0], sc[1], pts[2] = 0, 1, None
+        bases, scalars = c.encode_affine_array(pts), m.encode_scalars(sc)
+        got = ea.msm(bases, scalars, c.name)
+        assert got == c.encode_projective_normalized(c.msm_pippenger(pts, sc) if n > 40 else c.msm_naive(pts, sc)), n
+    # one hot bucket, cancellation to infinity, shard-and-fold
+    n = 2000
+    bases = ea.generate_points(n, distinct=16, seed=2, curve=c.name)
+    ctx = ea.multi_scalar_mult_init(bases, c.name)
+    same = np.tile(rand_scalars_np(0, 1, 3), (n, 1))
+    assert ea.multi_scalar_mult(ctx, bases, same)[0] == _oracle_g2(oracle, bases, np.ascontiguousarray(same), n)
+    sc = rand_scalars_np(0, n, 4)
+    whole = ea.multi_scalar_mult(ctx, bases, sc)[0]
+    lo = ctx.run(np.ascontiguousarray(sc[:n // 2]), npoints=n // 2)[0]
+    ctx2 = ea.multi_scalar_mult_init(np.ascontiguousarray(bases[n // 2:]), c.name)
+    hi = ctx2.run(np.ascontiguousarray(sc[n // 2:]))[0]
+    assert ea.fold_partials([lo, hi], c.name) == whole == _oracle_g2(oracle, bases, sc, n)
+    ctx.close()
+    ctx2.close()
+
+
+@pytest.mark.parametrize("npow", [20, 24])
+def test_g2_full_size_properties(ea, oracle, torch_cuda, npow):
+    """BLS12-377 G2 at 2^24 pairs (BASELINE.json configs[4]): linearity + prefix parity (the CPU oracle needs minutes at this size)."""
+    torch = torch_cuda
+    n = 1 << npow
+    distinct = 1 << 12
+    tile = ea.generate_points(distinct, distinct=distinct, seed=6, curve="bls12_377_g2")
+    bases = torch.from_numpy(tile).cuda().repeat(n // distinct, 1).contiguous()
+    g = torch.Generator(device="cuda")
+    g.manual_seed(npow)
+    k1 = torch.randint(-(1 << 63), (1 << 63) - 1, (n, 4), dtype=torch.int64, device="cuda", generator=g)
+    k1[:, 3] &= (1 << 59) - 1
+    k2 = torch.randint(-(1 << 63), (1 << 63) - 1, (n, 4), dtype=torch.int64, device="cuda", generator=g)
+    k2[:, 3] &= (1 << 59) - 1
+    k2[:, :3] = 0            # k2 = t * 2^192: adding it touches only the top limb, no carries
+    as_bytes = lambda t: t.view(torch.uint8).reshape(-1, 32)
+    ksum = k1.clone()
+    ksum[:, 3] += k2[:, 3]
+    ctx = ea.MultiScalarMultContext("bls12_377_g2")
+    ctx.set_bases(bases)
+    r1 = ctx.run(as_bytes(k1))[0]
+    r2 = ctx.run(as_bytes(k2))[0]
+    r12 = ctx.run(as_bytes(ksum))[0]
+    assert ea.fold_partials([r1, r2], "bls12_377_g2") == r12
+    sample = 1 << 13
+    sc = as_bytes(k1[:sample].contiguous()).cpu().numpy()
+    assert ctx.run(as_bytes(k1[:sample].contiguous()), npoints=sample)[0] == _oracle_g2(
+        oracle, np.ascontiguousarray(np.tile(tile, (sample // distinct, 1))), sc, sample)
+    print("G2 2^%d timings: %s" % (npow, ctx.last_timings()))
     ctx.close()
 
 

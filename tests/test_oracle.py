@@ -51,8 +51,12 @@ def test_window_rule(oracle):
 def test_golden_vectors(oracle, golden):
     for case in golden:
         cid = m.CURVES[case["curve"]].curve_id
-        got = oracle_msm(oracle, cid, bytes.fromhex(case["bases"]), bytes.fromhex(case["scalars"]), case["n"])
-        assert got.hex() == case["expected"], case["name"]
+        c = m.CURVES[case["curve"]]
+        out = ctypes.create_string_buffer(c.projective_bytes)
+        bases, scalars = bytes.fromhex(case["bases"]), bytes.fromhex(case["scalars"])
+        assert oracle.oracle_msm(cid, ctypes.create_string_buffer(bases, len(bases)), c.affine_stride,
+                                 ctypes.create_string_buffer(scalars, len(scalars)), case["n"], out, 0) == 0
+        assert out.raw.hex() == case["expected"], case["name"]
 
 
 def test_edge_fixtures_are_infinity(golden):

@@ -106,6 +106,22 @@ def main():
     pts[16], pts[31], pts[47], pts[63] = m.EDGE_P, m.EDGE_T, m.EDGE_P_NEG, m.EDGE_T
     cases.append(case("fpga_edge4_boundaries", c, pts, m.random_scalars(c, 64, rng),
                       "P1B msm_unit_tests.rs:187-242 (scaled down): special points at chunk boundaries"))
+    # BLS12-377 G2 (Fq2 coordinates, 200-byte Affine images); pinned by the Python model and the C oracle, whose Fp2
+    # arithmetic is pinned by the reference's Fq2 KATs (tests/golden/fq2_kat_bls12_381.json)
+    g2 = m.BLS12_377_G2
+    rng = random.Random(0xC0FFEE + 2)
+    for n, distinct in ((1, 1), (5, 3), (33, 8), (100, 10)):
+        pts = m.random_points(g2, n, rng, distinct)
+        sc = m.random_scalars(g2, n, rng)
+        cases.append(case(f"random_n{n}", g2, pts, sc, "G2: uniform scalars < r; replicated bases", check_ref=False))
+    pts = m.random_points(g2, 24, rng, 4)
+    sc = m.random_scalars(g2, 24, rng)
+    sc[0], sc[1], sc[2] = 0, 1, g2.r - 1
+    pts[5] = None
+    cases.append(case("special_scalars_and_infinity", g2, pts, sc, "G2: 0, 1, r-1 scalars and an infinity base", check_ref=False))
+    gg = g2.generator()
+    cases.append(case("alternating_pm_generator", g2, [gg if i % 2 == 0 else g2.neg(gg) for i in range(16)], [sc[6]] * 16,
+                      "G2: +G, -G with one scalar -> infinity", check_ref=False))
     with open(os.path.join(OUT, "msm_vectors.json"), "w") as f:
         json.dump({"generator": "tools/gen_golden.py", "cases": cases}, f, indent=0)
     print("wrote", len(cases), "cases")
