@@ -25,7 +25,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
-BYTES_PER_PAIR = 128.0          # 32 B scalar + 96 B affine base
+BYTES_PER_PAIR = {0: 128.0, 1: 128.0, 2: 224.0}   # 32 B scalar + 96 B affine base (G2: + 192 B)
 R377_TOP = 0x12ab655e9a2ca556   # top 64-bit limb of the BLS12-377 scalar modulus (ARKC bls12_377/src/fields/fr.rs:24)
 R381_TOP = 0x73eda753299d7d48
 
@@ -52,9 +52,9 @@ def uniform_scalars(n, top_limb, device, seed):
 def cpu_baseline(curve, cid, bases_np, scalars_np, sample, threads):
     """Time the oracle (arkworks-algorithm restatement) on `sample` pairs; returns (pairs/s, result bytes, seconds)."""
     lib = ctypes.CDLL(os.path.join(ROOT, "oracle", "liboracle.so"))
-    out = ctypes.create_string_buffer(144)
+    out = ctypes.create_string_buffer(288 if cid == 2 else 144)
     t0 = time.perf_counter()
-    rc = lib.oracle_msm(cid, bases_np.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(104),
+    rc = lib.oracle_msm(cid, bases_np.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(bases_np.shape[1]),
                         scalars_np.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(sample), out, threads)
     dt = time.perf_counter() - t0
     if rc != 0:
@@ -68,7 +68,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--npow", type=int, default=26, help="log2 pairs per GPU (26 = ZPrize prize1-msm canonical size)")
-    ap.add_argument("--curve", default="bls12_377_g1", choices=["bls12_377_g1", "bls12_381_g1"])
+    ap.add_argument("--curve", default="bls12_377_g1", choices=["bls12_377_g1", "bls12_381_g1", "bls12_377_g2"])
     ap.add_argument("--cpu-sample-pow", type=int, default=24, help="log2 pairs of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--window-bits", type=int, default=0)
     ap.add_argument("--lane-entries", type=int, default=0)
@@ -102,7 +102,7 @@ def main():
     base_tile = ea.generate_points(distinct, distinct=distinct, seed=0x5A5052495A45 + cid, curve=args.curve)
     tile = torch.from_numpy(base_tile).to(device)
     bases = tile.repeat(n // distinct, 1).contiguous()
-    scalars = uniform_scalars(n, R377_TOP if cid == 0 else R381_TOP, device, seed=1234 + rank)
+    scalars = uniform_scalars(n, R381_TOP if cid == 1 else R377_TOP, device, seed=1234 + rank)
     ctx = ea.MultiScalarMultContext(args.curve, device=local_rank)
     ctx.set_bases(bases)
     del bases
@@ -147,9 +147,18 @@ def main():
         value = pairs_per_step * args.steps / elapsed
         kern_s = (acc_ms / max(acc_launches, 1)) * 1e-3
         pairs_per_launch = n * args.steps / max(acc_launches, 1)
-        achieved = BYTES_PER_PAIR * pairs_per_launch / kern_s / 1e9
+        achieved = BYTES_PER_PAIR[cid] * pairs_per_launch / kern_s / 1e9
+        # HBM traffic and VALU occupancy of the dominant kernel come from separate rocprofv3 --pmc passes (committed under
+        # profiles/); they are only quoted for the configuration they were measured on
+        traffic, valu = None, None
+        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_k_accumulate.json")
+        if cid == 0 and args.npow == 26 and not args.window_bits and not args.lane_entries and os.path.exists(pmc_path):
+            pmc = json.load(open(pmc_path))
+            traffic = pmc["traffic_bytes_raw"]
+            valu = {"busy_fraction": pmc["derived"]["valu_busy_fraction"], "effective_clock_GHz": pmc["derived"]["effective_clock_GHz"],
+                    "valu_instr_per_mixed_add": pmc["derived"]["valu_instr_per_mixed_add"], "source": "profiles/r01_pmc_k_accumulate.json"}
         out = {
-            "metric": "BLS12-377 G1 MSM point-scalar pairs/s" if cid == 0 else "BLS12-381 G1 MSM point-scalar pairs/s",
+            "metric": {0: "BLS12-377 G1", 1: "BLS12-381 G1", 2: "BLS12-377 G2"}[cid] + " MSM point-scalar pairs/s",
             "value": value,
             "unit": "pairs/s",
             "n_gpus": world,
@@ -164,20 +173,23 @@ def main():
             "data": "synthetic: 2^15 distinct subgroup points replicated (reference generator shape), uniform scalars < r",
             "config": {"workload": f"{args.curve} MSM, 2^{args.npow} pairs per GPU, bases+scalars resident in HBM",
                        "pairs_per_gpu": n, "window_bits": tm["window_bits"], "windows": tm["windows"],
-                       "lane_entries": tm["lane_entries"], "parallelism": f"{world} disjoint base/scalar slices + all-gather of {world}x144 B"},
+                       "lane_entries": tm["lane_entries"], "parallelism": f"{world} disjoint base/scalar slices + all-gather of {world} partial points"},
             "stage_ms_per_step": {k: v / args.steps for k, v in stage_ms.items()},
             "roofline": {"bound": "hbm", "kernel": "k_accumulate", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                         "kernel_ms": kern_s * 1e3, "algorithmic_bytes_per_launch": BYTES_PER_PAIR * pairs_per_launch,
-                         "note": "integer-VALU-bound path (no MFMA); see DESIGN.md for the v_mad_u64_u32 issue-rate roofline"},
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "kernel_ms": kern_s * 1e3, "algorithmic_bytes_per_launch": BYTES_PER_PAIR[cid] * pairs_per_launch,
+                         "valu": valu,
+                         "note": "integer-VALU-bound path (no MFMA): the binding resource is VALU issue (DESIGN.md section 5)"},
         }
         if world == 1 and args.cpu_sample_pow > 0:
             sample = min(n, 1 << args.cpu_sample_pow)
             cores = os.cpu_count() or 1
+            if cid == 2:
+                sample = min(sample, 1 << 21)   # Fp2 arithmetic is ~3x slower on the CPU too
             bases_np = np.ascontiguousarray(np.tile(base_tile, (max(1, sample // distinct), 1))[:sample])
             scal_np = scalars[:sample].cpu().numpy()
             c = 3 if sample < 32 else (((sample - 1).bit_length()) * 69 // 100 + 2)
-            windows = -(-(253 if cid == 0 else 255) // c)
+            windows = -(-(255 if cid == 1 else 253) // c)
             threads = min(windows, cores)
             v, cpu_res, dt = cpu_baseline(args.curve, cid, bases_np, scal_np, sample, threads)
             # same sample on the GPU: a parity spot-check next to the number
