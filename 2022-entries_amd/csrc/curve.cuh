@@ -124,6 +124,72 @@ struct Fp2El {
   static MSM_HD void reduce(T& r) { fe_reduce<F>(r.c0); fe_reduce<F>(r.c1); }
 };
 
+// ---- inversion in the coordinate field (host fold, and the device precompute/normalise kernels) ------------------
+// limb i (radix 2^28) of p - 2, with the borrow carried through low limbs that are < 2 (BLS12-377 has p = 1 mod 2^28)
+template <class F>
+constexpr uint32_t pm2_limb(int i) {
+  int64_t borrow = 2;
+  uint32_t out = 0;
+  for (int k = 0; k <= i; k++) {
+    int64_t d = (int64_t)F::P[k] - borrow;
+    if (d < 0) {
+      d += (int64_t)1 << LB;
+      borrow = 1;
+    } else {
+      borrow = 0;
+    }
+    out = (uint32_t)d;
+  }
+  return out;
+}
+
+// a^(p-2) by square-and-multiply over the bits of p-2 (class-M in, class-M out); a == 0 gives 0.
+template <class F>
+MSM_HD void fe_inv(Fe& r, const Fe& a, const Modulus<F>& md) {
+  Fe acc;
+  fe_set(acc, F::ONE);
+  bool started = false;
+#pragma unroll
+  for (int i = NL - 1; i >= 0; i--) {
+    const uint32_t e = pm2_limb<F>(i);
+#pragma unroll 1
+    for (int b = LB - 1; b >= 0; b--) {
+      if (started) fe_sqr<F>(acc, acc, md);
+      if ((e >> b) & 1) {
+        if (started) {
+          fe_mul<F>(acc, acc, a, md);
+        } else {
+          acc = a;
+          started = true;
+        }
+      }
+    }
+  }
+  r = acc;
+}
+
+template <class F>
+MSM_HD void el_inv(Fe& r, const Fe& a, const Modulus<F>& md, FpEl<F>*) {
+  fe_inv<F>(r, a, md);
+}
+// (a0 + a1 u)^-1 = (a0 - a1 u) / (a0^2 - BETA a1^2)   (quadratic_extension.rs:323)
+template <class F, int NB>
+MSM_HD void el_inv(Fe2& r, const Fe2& a, const Modulus<F>& md, Fp2El<F, NB>*) {
+  Fe n0, n1, n, ni, t, one;
+  fe_sqr<F>(n0, a.c0, md);
+  fe_sqr<F>(n1, a.c1, md);
+#pragma unroll
+  for (int i = 0; i < NL; i++) n.v[i] = n0.v[i] + n1.v[i] * (uint32_t)NB;   // a0^2 + NB a1^2, < 9p, limbs < 6*2^28
+  fe_carry(n);
+  fe_set(one, F::ONE);
+  fe_mul<F>(n, n, one, md);   // back to class M (n * R * R^-1)
+  fe_inv<F>(ni, n, md);
+  fe_mul<F>(r.c0, a.c0, ni, md);
+  fe_mul<F>(t, a.c1, ni, md);
+  fe_neg(r.c1, t, F::BIAS2_28);
+  fe_carry(r.c1);
+}
+
 template <class E>
 MSM_HD void xyzz_set_inf(XyzzT<typename E::T>& r) {
   E::zero(r.x);

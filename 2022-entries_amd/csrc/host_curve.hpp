@@ -10,64 +10,6 @@
 
 namespace msm {
 
-// a^(p-2) by square-and-multiply over the bits of p-2 (class-M in, class-M out).
-template <class F>
-inline void fe_inv(Fe& r, const Fe& a, const Modulus<F>& md) {
-  // exponent e = p - 2 in radix-2^28 limbs
-  uint32_t e[NL];
-  int64_t borrow = -2;
-  for (int i = 0; i < NL; i++) {
-    int64_t d = (int64_t)F::P[i] + borrow;
-    if (d < 0) {
-      e[i] = (uint32_t)(d + (1 << LB));
-      borrow = -1;
-    } else {
-      e[i] = (uint32_t)d;
-      borrow = 0;
-    }
-  }
-  Fe acc;
-  fe_set(acc, F::ONE);
-  bool started = false;
-  for (int i = NL - 1; i >= 0; i--) {
-    for (int b = LB - 1; b >= 0; b--) {
-      if (started) fe_sqr<F>(acc, acc, md);
-      if ((e[i] >> b) & 1) {
-        if (started) {
-          fe_mul<F>(acc, acc, a, md);
-        } else {
-          acc = a;
-          started = true;
-        }
-      }
-    }
-  }
-  r = acc;
-}
-
-// Inverse in the coordinate field (host only).
-template <class F>
-inline void el_inv(Fe& r, const Fe& a, const Modulus<F>& md, FpEl<F>*) {
-  fe_inv<F>(r, a, md);
-}
-// (a0 + a1 u)^-1 = (a0 - a1 u) / (a0^2 - BETA a1^2)   (quadratic_extension.rs:323)
-template <class F, int NB>
-inline void el_inv(Fe2& r, const Fe2& a, const Modulus<F>& md, Fp2El<F, NB>*) {
-  Fe n0, n1, n, ni, t;
-  fe_sqr<F>(n0, a.c0, md);
-  fe_sqr<F>(n1, a.c1, md);
-  for (int i = 0; i < NL; i++) n.v[i] = n0.v[i] + n1.v[i] * (uint32_t)NB;   // a0^2 + NB a1^2, < 9p, limbs < 6*2^28
-  fe_carry(n);
-  Fe one;
-  fe_set(one, F::ONE);
-  fe_mul<F>(n, n, one, md);   // back to class M (value unchanged mod p: n * R * R^-1)
-  fe_inv<F>(ni, n, md);
-  fe_mul<F>(r.c0, a.c0, ni, md);
-  fe_mul<F>(t, a.c1, ni, md);
-  fe_neg(r.c1, t, F::BIAS2_28);
-  fe_carry(r.c1);
-}
-
 // arkworks Affine image (x, y in the ABI Montgomery radix, infinity flag after the two coordinates) -> internal Affine.
 // The flag byte is authoritative (zero is (0,1,true) in ark 0.3 and (0,0,true) in 0.4).
 template <class E>
@@ -143,16 +85,19 @@ inline void fold_windows(XyzzT<typename E::T>& acc, const XyzzT<typename E::T>* 
 struct Bls12_377_G1 {
   using E = FpEl<Bls12_377_Fq>;
   using FR = Bls12_377_Fr;
+  static constexpr int SCALAR_BITS = 253;
   static void generator(AffineT<Fe>& g) { fe_set(g.x, Bls12_377_Fq::G1X); fe_set(g.y, Bls12_377_Fq::G1Y); }
 };
 struct Bls12_381_G1 {
   using E = FpEl<Bls12_381_Fq>;
   using FR = Bls12_381_Fr;
+  static constexpr int SCALAR_BITS = 255;
   static void generator(AffineT<Fe>& g) { fe_set(g.x, Bls12_381_Fq::G1X); fe_set(g.y, Bls12_381_Fq::G1Y); }
 };
 struct Bls12_377_G2 {
   using E = Fp2El<Bls12_377_Fq, 5>;
   using FR = Bls12_377_Fr;
+  static constexpr int SCALAR_BITS = 253;
   static void generator(AffineT<Fe2>& g) {
     fe_set(g.x.c0, Bls12_377_Fq::G2X0); fe_set(g.x.c1, Bls12_377_Fq::G2X1);
     fe_set(g.y.c0, Bls12_377_Fq::G2Y0); fe_set(g.y.c1, Bls12_377_Fq::G2Y1);

@@ -38,4 +38,17 @@ hipError_t Launch<E>::bucket_reduce(bool first, const XyzzDevT<El>* in_a, const 
   return hipGetLastError();
 }
 
+template <class E>
+hipError_t Launch<E>::pre_double(const AffineDevT<El>* in, const uint8_t* inf_in, uint32_t n, uint32_t c, XyzzDevT<El>* out, hipStream_t st) {
+  hipLaunchKernelGGL((k_pre_double<E>), dim3(launch_blocks(n)), dim3(256), 0, st, in, inf_in, n, c, out);
+  return hipGetLastError();
+}
+
+template <class E>
+hipError_t Launch<E>::pre_normalize(const XyzzDevT<El>* in, uint32_t n, uint32_t J, El* prefix, AffineDevT<El>* out, uint8_t* inf_out,
+                                    hipStream_t st) {
+  hipLaunchKernelGGL((k_pre_normalize<E>), dim3(launch_blocks(((uint64_t)n + J - 1) / J)), dim3(256), 0, st, in, n, J, prefix, out, inf_out);
+  return hipGetLastError();
+}
+
 }  // namespace msm

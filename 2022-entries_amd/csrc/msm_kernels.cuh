@@ -200,4 +200,77 @@ __global__ void __launch_bounds__(256) k_bucket_reduce(const XyzzDevT<typename E
   out_x[g] = o;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Fixed-base precompute (row f1): table level w holds 2^(c w) * P_i as affine points, so every digit of a scalar feeds
+// ONE shared bucket set and the bucket->window reduction and the Horner fold shrink by the number of windows
+// (CMB PrecomputePoints.cu:10-39 builds 2^(46k) P the same way; P1A matter-labs/src/lib.rs:101-114).
+// Step 1: XYZZ = 2^c * (level w-1), one thread per point.
+template <class E>
+__global__ void __launch_bounds__(256) k_pre_double(const AffineDevT<typename E::T>* __restrict__ in, const uint8_t* __restrict__ inf_in,
+                                                    uint32_t n, uint32_t c, XyzzDevT<typename E::T>* __restrict__ out) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  typename E::Md md;
+  XyzzDevT<typename E::T> o;
+  if (inf_in[i]) {
+    xyzz_set_inf<E>(o.p);
+  } else {
+    const AffineDevT<typename E::T> a = in[i];
+    xyzz_from_affine<E>(o.p, a.p, false);
+    for (uint32_t k = 0; k < c; k++) xyzz_dbl<E>(o.p, md);
+  }
+  out[i] = o;
+}
+
+// Step 2: back to affine with one inversion per lane (Montgomery's trick over J consecutive points): forward pass stores
+// the running products of zz*zzz, the backward pass peels one inverse per point.  A point that became infinity
+// (a low-order base doubled away) is written as zeros and flagged.
+template <class E>
+__global__ void __launch_bounds__(256) k_pre_normalize(const XyzzDevT<typename E::T>* __restrict__ in, uint32_t n, uint32_t J,
+                                                       typename E::T* __restrict__ prefix, AffineDevT<typename E::T>* __restrict__ out,
+                                                       uint8_t* __restrict__ inf_out) {
+  using El = typename E::T;
+  const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+  const uint64_t lo = (uint64_t)t * J;
+  if (lo >= n) return;
+  const uint64_t hi = (lo + J < n) ? lo + J : n;
+  typename E::Md md;
+  El run;
+  E::set_one(run);
+  for (uint64_t j = lo; j < hi; j++) {
+    const XyzzDevT<El> v = in[j];
+    prefix[j] = run;
+    if (!xyzz_is_inf<E>(v.p)) {
+      El z;
+      E::mul(z, v.p.zz, v.p.zzz, md);
+      E::mul(run, run, z, md);
+    }
+  }
+  El inv;
+  el_inv(inv, run, md, (E*)nullptr);
+  for (uint64_t j = hi; j-- > lo;) {
+    const XyzzDevT<El> v = in[j];
+    AffineDevT<El> o;
+    if (xyzz_is_inf<E>(v.p)) {
+      E::zero(o.p.x);
+      E::zero(o.p.y);
+      inf_out[j] = 1;
+    } else {
+      El z, ti, zzi, zzzi;
+      const El pre = prefix[j];
+      E::mul(ti, inv, pre, md);          // (zz_j zzz_j)^-1
+      E::mul(z, v.p.zz, v.p.zzz, md);
+      E::mul(inv, inv, z, md);
+      E::mul(zzi, ti, v.p.zzz, md);
+      E::mul(zzzi, ti, v.p.zz, md);
+      E::mul(o.p.x, v.p.x, zzi, md);
+      E::mul(o.p.y, v.p.y, zzzi, md);
+      E::reduce(o.p.x);
+      E::reduce(o.p.y);
+      inf_out[j] = 0;
+    }
+    out[j] = o;
+  }
+}
+
 }  // namespace msm

@@ -70,6 +70,7 @@ def main():
     ap.add_argument("--npow", type=int, default=26, help="log2 pairs per GPU (26 = ZPrize prize1-msm canonical size)")
     ap.add_argument("--curve", default="bls12_377_g1", choices=["bls12_377_g1", "bls12_381_g1", "bls12_377_g2"])
     ap.add_argument("--cpu-sample-pow", type=int, default=24, help="log2 pairs of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--precompute", type=int, default=0, help="1 = context with precomputed 2^(c w) P tables (row f1; init untimed)")
     ap.add_argument("--window-bits", type=int, default=0)
     ap.add_argument("--lane-entries", type=int, default=0)
     args = ap.parse_args()
@@ -104,10 +105,15 @@ def main():
     bases = tile.repeat(n // distinct, 1).contiguous()
     scalars = uniform_scalars(n, R381_TOP if cid == 1 else R377_TOP, device, seed=1234 + rank)
     ctx = ea.MultiScalarMultContext(args.curve, device=local_rank)
-    ctx.set_bases(bases)
-    del bases
     if args.window_bits:
         ctx.set_option("window_bits", args.window_bits)
+    if args.precompute:
+        ctx.set_option("precompute", 1)
+    t_init = time.perf_counter()
+    ctx.set_bases(bases)
+    torch.cuda.synchronize()
+    t_init = time.perf_counter() - t_init
+    del bases
     if args.lane_entries:
         ctx.set_option("lane_entries", args.lane_entries)
 
@@ -152,7 +158,7 @@ def main():
         # profiles/); they are only quoted for the configuration they were measured on
         traffic, valu = None, None
         pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_k_accumulate.json")
-        if cid == 0 and args.npow == 26 and not args.window_bits and not args.lane_entries and os.path.exists(pmc_path):
+        if cid == 0 and args.npow == 26 and not args.window_bits and not args.lane_entries and not args.precompute and os.path.exists(pmc_path):
             pmc = json.load(open(pmc_path))
             traffic = pmc["traffic_bytes_raw"]
             valu = {"busy_fraction": pmc["derived"]["valu_busy_fraction"], "effective_clock_GHz": pmc["derived"]["effective_clock_GHz"],
@@ -173,7 +179,7 @@ def main():
             "data": "synthetic: 2^15 distinct subgroup points replicated (reference generator shape), uniform scalars < r",
             "config": {"workload": f"{args.curve} MSM, 2^{args.npow} pairs per GPU, bases+scalars resident in HBM",
                        "pairs_per_gpu": n, "window_bits": tm["window_bits"], "windows": tm["windows"],
-                       "lane_entries": tm["lane_entries"], "parallelism": f"{world} disjoint base/scalar slices + all-gather of {world} partial points"},
+                       "lane_entries": tm["lane_entries"], "precompute": bool(args.precompute), "init_s": t_init, "parallelism": f"{world} disjoint base/scalar slices + all-gather of {world} partial points"},
             "stage_ms_per_step": {k: v / args.steps for k, v in stage_ms.items()},
             "roofline": {"bound": "hbm", "kernel": "k_accumulate", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,

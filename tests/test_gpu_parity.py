@@ -161,6 +161,40 @@ def test_montgomery_form_scalars(ea, oracle, torch_cuda, cid, curve):
     ctx.close()
 
 
+@pytest.mark.parametrize("cid,curve", CURVES)
+def test_precomputed_tables(ea, oracle, golden, torch_cuda, cid, curve):
+    """Row f1: a context with precomputed 2^(c w) P tables (all digits share one bucket set) returns the same bytes,
+    for random inputs, for prefixes, with chunking, and for the low-order edge points (whose multiples hit infinity)."""
+    n = 1 << 13
+    bases = ea.generate_points(n, distinct=500, seed=12, curve=curve.name)
+    bases[7, 96] = 1                      # a base flagged infinite
+    scalars = rand_scalars_np(cid, 2 * n, 31)
+    exp = [oracle_msm_np(oracle, cid, bases, np.ascontiguousarray(scalars[b * n:(b + 1) * n]), n) for b in range(2)]
+    ctx = ea.MultiScalarMultContext(curve.name)
+    ctx.set_option("precompute", 1)
+    ctx.set_bases(bases)
+    assert ctx.run(scalars) == exp
+    t = ctx.last_timings()
+    assert t["windows"] * n == t["entries"]
+    assert ctx.run(np.ascontiguousarray(scalars[:1000]), npoints=1000)[0] == oracle_msm_np(
+        oracle, cid, bases, np.ascontiguousarray(scalars[:1000]), 1000)
+    ctx.set_option("max_chunk", 3000)
+    assert ctx.run(scalars) == exp
+    with pytest.raises(ea.MsmError):
+        ctx.set_option("window_bits", 5)   # fixed by the tables
+    ctx.close()
+    for case in golden:
+        if case["curve"] != curve.name:
+            continue
+        b, sc = bytes.fromhex(case["bases"]), bytes.fromhex(case["scalars"])
+        ctx = ea.MultiScalarMultContext(curve.name)
+        ctx.set_option("precompute", 1)
+        ctx.set_option("window_bits", 6)
+        ctx.set_bases(b)
+        assert ctx.run(sc)[0].hex() == case["expected"], case["name"]
+        ctx.close()
+
+
 def test_prefix_run_and_errors(ea, oracle, torch_cuda):
     c = m.BLS12_377_G1
     n = 600
