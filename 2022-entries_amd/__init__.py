@@ -19,3 +19,4 @@ from .msm import (  # noqa: F401
     msm,
 )
 from .dist import all_gather_partials, shard_bounds, sharded_msm  # noqa: F401,E402
+from . import formats  # noqa: F401,E402

@@ -56,6 +56,21 @@ struct FpEl {
   static MSM_HD void from_abi(T& r, const uint32_t* w, const Md& md) { fe_from_abi<F>(r, w, md); }
   static MSM_HD void to_abi(uint32_t* w, const T& a, const Md& md) { fe_to_abi<F>(w, a, md); }
   static MSM_HD void reduce(T& r) { fe_reduce<F>(r); }
+  // normal-form integers (arkworks CanonicalSerialize: little-endian, not Montgomery) <-> internal
+  static MSM_HD void from_plain(T& r, const uint32_t* w, const Md& md) {
+    Fe t, c;
+    fe_from_words(t, w);
+    fe_set(c, F::RR);
+    fe_mul<F>(r, t, c, md);
+  }
+  static MSM_HD void to_plain(uint32_t* w, const T& a, const Md& md) {
+    Fe t, one;
+    fe_zero(one);
+    one.v[0] = 1;
+    fe_mul<F>(t, a, one, md);   // x*R * 1 * R^-1 = x
+    fe_reduce<F>(t);
+    fe_to_words(w, t);
+  }
 };
 
 struct Fe2 {
@@ -122,6 +137,14 @@ struct Fp2El {
     fe_to_abi<F>(w + 12, a.c1, md);
   }
   static MSM_HD void reduce(T& r) { fe_reduce<F>(r.c0); fe_reduce<F>(r.c1); }
+  static MSM_HD void from_plain(T& r, const uint32_t* w, const Md& md) {
+    FpEl<F>::from_plain(r.c0, w, md);
+    FpEl<F>::from_plain(r.c1, w + 12, md);
+  }
+  static MSM_HD void to_plain(uint32_t* w, const T& a, const Md& md) {
+    FpEl<F>::to_plain(w, a.c0, md);
+    FpEl<F>::to_plain(w + 12, a.c1, md);
+  }
 };
 
 // ---- inversion in the coordinate field (host fold, and the device precompute/normalise kernels) ------------------

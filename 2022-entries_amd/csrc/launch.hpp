@@ -12,7 +12,8 @@ namespace msm {
 template <class E>
 struct Launch {
   using El = typename E::T;
-  static hipError_t convert_bases(const uint8_t* in, size_t stride, uint32_t n, AffineDevT<El>* out, uint8_t* inf, hipStream_t st);
+  static hipError_t convert_bases(const uint8_t* in, size_t stride, uint32_t n, bool serialized, AffineDevT<El>* out, uint8_t* inf,
+                                  hipStream_t st);
   static hipError_t accumulate(const uint32_t* keys, const uint32_t* vals, uint32_t n_entries, uint32_t K, uint32_t sentinel,
                                const AffineDevT<El>* bases, SegOutT<El> out, uint32_t nlanes, hipStream_t st);
   static hipError_t segreduce(const XyzzDevT<El>* in_slots, const uint32_t* in_keys, uint32_t n_in, uint32_t K, SegOutT<El> out,

@@ -8,8 +8,12 @@ namespace msm {
 inline uint32_t launch_blocks(uint64_t n) { return (uint32_t)((n + 255) / 256); }
 
 template <class E>
-hipError_t Launch<E>::convert_bases(const uint8_t* in, size_t stride, uint32_t n, AffineDevT<El>* out, uint8_t* inf, hipStream_t st) {
-  hipLaunchKernelGGL((k_convert_bases<E>), dim3(launch_blocks(n)), dim3(256), 0, st, in, stride, n, out, inf);
+hipError_t Launch<E>::convert_bases(const uint8_t* in, size_t stride, uint32_t n, bool serialized, AffineDevT<El>* out, uint8_t* inf,
+                                    hipStream_t st) {
+  if (serialized)
+    hipLaunchKernelGGL((k_convert_bases<E, true>), dim3(launch_blocks(n)), dim3(256), 0, st, in, stride, n, out, inf);
+  else
+    hipLaunchKernelGGL((k_convert_bases<E, false>), dim3(launch_blocks(n)), dim3(256), 0, st, in, stride, n, out, inf);
   return hipGetLastError();
 }
 

@@ -140,6 +140,7 @@ struct mi355_msm_ctx {
   long opt_precompute = 0;
   // precomputed tables (row f1): level w at bases[w * nbases ...] holds 2^(pre_c * w) * P; 0 = none
   uint32_t pre_c = 0, pre_windows = 0;
+  bool bases_serialized = false;  // set only for the duration of mi355_msm_set_bases_serialized
   float last_ms[MI355_T_COUNT] = {};
   uint64_t last_info[8] = {};
 
@@ -157,7 +158,7 @@ struct mi355_msm_ctx {
     p.sentinel = p.bucket_windows * p.half;
     p.keybits = ilog2_floor(p.sentinel) + 1;
     p.entries = (uint64_t)p.windows * n;
-    uint32_t K = opt_lane_entries ? (uint32_t)opt_lane_entries : (uint32_t)std::min<uint64_t>(128, std::max<uint64_t>(8, p.entries >> 20));
+    uint32_t K = opt_lane_entries ? (uint32_t)opt_lane_entries : (uint32_t)std::min<uint64_t>(256, std::max<uint64_t>(8, p.entries >> 20));
     p.K = (K + 3) & ~3u;
     p.nlanes = ceil_div(p.entries, p.K);
     p.segK = opt_seg_entries >= 4 ? (uint32_t)opt_seg_entries : 8;
@@ -194,7 +195,7 @@ void convert_bases(mi355_msm_ctx* ctx, const uint8_t* d_raw, size_t n, size_t st
   using AD = AffineDevT<typename E::T>;
   ctx->bases.reserve(n * sizeof(AD));
   ctx->inf.reserve(n);
-  HIP_OK(Launch<E>::convert_bases(d_raw, stride, (uint32_t)n, ctx->bases.as<AD>(), ctx->inf.as<uint8_t>(), st));
+  HIP_OK(Launch<E>::convert_bases(d_raw, stride, (uint32_t)n, ctx->bases_serialized, ctx->bases.as<AD>(), ctx->inf.as<uint8_t>(), st));
 }
 
 // Build the tables 2^(c w) * P_i, w = 1 .. windows-1, behind the converted bases (level 0).
@@ -214,7 +215,7 @@ void build_tables(mi355_msm_ctx* ctx, const uint8_t* d_raw, size_t n, size_t str
     bad_arg("precompute: %u tables of %zu points need %zu MiB, only %zu MiB free", windows, n, table_bytes >> 20, free_b >> 20);
   ctx->bases.reserve(table_bytes);
   ctx->inf.reserve((size_t)windows * n);
-  HIP_OK(Launch<E>::convert_bases(d_raw, stride, (uint32_t)n, ctx->bases.as<AD>(), ctx->inf.as<uint8_t>(), st));
+  HIP_OK(Launch<E>::convert_bases(d_raw, stride, (uint32_t)n, ctx->bases_serialized, ctx->bases.as<AD>(), ctx->inf.as<uint8_t>(), st));
   DevBuf xyzz, prefix;
   try {
     xyzz.reserve(n * sizeof(XD));
@@ -242,7 +243,7 @@ void build_tables(mi355_msm_ctx* ctx, const uint8_t* d_raw, size_t n, size_t str
 
 void set_bases_device(mi355_msm_ctx* ctx, const void* d_affine, size_t n, size_t stride) {
   ensure_device(ctx);
-  const size_t min_stride = 2 * coord_bytes(ctx->curve) + 1;
+  const size_t min_stride = 2 * coord_bytes(ctx->curve) + (ctx->bases_serialized ? 0 : 1);
   if (stride < min_stride || (stride & 3)) bad_arg("affine stride %zu is not a 4-byte multiple >= %zu", stride, min_stride);
   if (n >= (1ull << 31)) bad_arg("npoints %zu exceeds 2^31-1", n);
   ctx->pre_c = ctx->pre_windows = 0;
@@ -480,6 +481,60 @@ RustError mi355_msm_set_bases(mi355_msm_ctx* ctx, const void* affine, size_t npo
       throw;
     }
     raw.release();
+  });
+}
+
+RustError mi355_msm_set_bases_serialized(mi355_msm_ctx* ctx, const void* records, size_t npoints) {
+  return guarded([&] {
+    if (!ctx) bad_arg("null context");
+    if (npoints && !records) bad_arg("null records pointer");
+    ensure_device(ctx);
+    const size_t stride = 2 * coord_bytes(ctx->curve);
+    DevBuf raw;
+    ctx->bases_serialized = true;
+    try {
+      if (npoints) {
+        raw.reserve(npoints * stride);
+        HIP_OK(hipMemcpy(raw.p, records, npoints * stride, hipMemcpyHostToDevice));
+      }
+      set_bases_device(ctx, raw.p, npoints, stride);
+    } catch (...) {
+      ctx->bases_serialized = false;
+      raw.release();
+      throw;
+    }
+    ctx->bases_serialized = false;
+    raw.release();
+  });
+}
+
+RustError mi355_msm_point_to_serialized(int curve, const void* projective, void* out_record) {
+  return guarded([&] {
+    if (!projective || !out_record) bad_arg("null pointer");
+    with_curve(curve, [&]<class C>() {
+      using E = typename C::E;
+      typename E::Md md;
+      constexpr int CB = 4 * E::WORDS;
+      XyzzT<typename E::T> p;
+      xyzz_from_projective_abi<E>(p, (const uint8_t*)projective, md);
+      uint8_t* out = (uint8_t*)out_record;
+      memset(out, 0, 2 * CB);
+      if (xyzz_is_inf<E>(p)) {
+        out[2 * CB - 1] = 0x40;   // SWFlags::Infinity
+        return;
+      }
+      typename E::T t, ti, zzi, zzzi, x, y;
+      E::mul(t, p.zz, p.zzz, md);
+      el_inv(ti, t, md, (E*)nullptr);
+      E::mul(zzi, ti, p.zzz, md);
+      E::mul(zzzi, ti, p.zz, md);
+      E::mul(x, p.x, zzi, md);
+      E::mul(y, p.y, zzzi, md);
+      uint32_t w[2 * E::WORDS];
+      E::to_plain(w, x, md);
+      E::to_plain(w + E::WORDS, y, md);
+      memcpy(out, w, 2 * CB);
+    });
   });
 }
 

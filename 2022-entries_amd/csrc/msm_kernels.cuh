@@ -23,7 +23,11 @@
 namespace msm {
 
 // ------------------------------------------------------------------------------------------------
-template <class E>
+// SERIALIZED = false: arkworks in-memory Affine images (Montgomery limbs, separate infinity flag byte).
+// SERIALIZED = true : arkworks CanonicalSerialize uncompressed records (row f2): x | y as little-endian NORMAL-form
+//                     integers, SWFlags in the top two bits of the last byte (bit 6 = infinity; P1B nickray
+//                     driver/algebra/serialize/src/flags.rs:107-134, ec/.../short_weierstrass_jacobian.rs:827-835).
+template <class E, bool SERIALIZED>
 __global__ void __launch_bounds__(256) k_convert_bases(const uint8_t* __restrict__ in, size_t stride, uint32_t n,
                                                        AffineDevT<typename E::T>* __restrict__ out, uint8_t* __restrict__ inf) {
   uint32_t i = blockIdx.x * 256 + threadIdx.x;
@@ -34,11 +38,22 @@ __global__ void __launch_bounds__(256) k_convert_bases(const uint8_t* __restrict
   uint32_t w[2 * W];
 #pragma unroll
   for (int k = 0; k < 2 * W; k++) w[k] = src[k];
-  uint8_t flag = in[(size_t)i * stride + 8 * W];
+  uint8_t flag;
+  if (SERIALIZED) {
+    flag = (w[2 * W - 1] >> 30) & 1;
+    w[2 * W - 1] &= 0x3fffffffu;
+  } else {
+    flag = in[(size_t)i * stride + 8 * W];
+  }
   AffineDevT<typename E::T> o;
   if (flag) {
     E::zero(o.p.x);
     E::zero(o.p.y);
+  } else if (SERIALIZED) {
+    E::from_plain(o.p.x, w, md);
+    E::from_plain(o.p.y, w + W, md);
+    E::reduce(o.p.x);
+    E::reduce(o.p.y);
   } else {
     E::from_abi(o.p.x, w, md);
     E::from_abi(o.p.y, w + W, md);

@@ -90,6 +90,8 @@ def load_library() -> ctypes.CDLL:
         "mi355_msm": [ci, vp, vp, sz, vp, sz],
         "mi355_msm_fold": [ci, vp, vp, sz],
         "mi355_msm_generate_points": [ci, ctypes.c_uint64, sz, sz, vp, sz],
+        "mi355_msm_set_bases_serialized": [vp, vp, sz],
+        "mi355_msm_point_to_serialized": [ci, vp, vp],
     }
     for name, args in sigs.items():
         fn = getattr(lib, name)

@@ -44,7 +44,7 @@ def uniform_scalars(n, top_limb, device, seed):
         nbad = int(bad.sum().item())
         if nbad == 0:
             break
-        top[bad] = torch.randint(0, 1 << bits, (nbad,), dtype=torch.int64, device=device, generator=g)
+        top[bad] = torch.randint(0, min(1 << bits, (1 << 63) - 1), (nbad,), dtype=torch.int64, device=device, generator=g)
     limbs[:, 3] = top
     return limbs.view(torch.uint8).reshape(n, 32)
 

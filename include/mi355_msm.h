@@ -76,6 +76,15 @@ RustError mi355_msm_set_bases(mi355_msm_ctx* ctx, const void* affine, size_t npo
 /* Same, bases already resident in DEVICE memory (e.g. a torch uint8 tensor's data_ptr). */
 RustError mi355_msm_set_bases_device(mi355_msm_ctx* ctx, const void* d_affine, size_t npoints, size_t stride);
 
+/* Bases as arkworks CanonicalSerialize UNCOMPRESSED records in host memory (row f2: what the harness persists with
+ * `points.serialize_unchecked(File::create("points.bin"))`, P1B hardcaml/.../test_fpga_harness/src/util.rs:126-140): per point
+ * x | y as little-endian normal-form integers (2 x 48 B for G1, 2 x 96 B for G2), SWFlags in the top two bits of the last
+ * byte (bit 6 = infinity).  Pass the records WITHOUT the leading u64 element count.  Converted on the device. */
+RustError mi355_msm_set_bases_serialized(mi355_msm_ctx* ctx, const void* records, size_t npoints);
+/* The inverse for results: a Projective image (any Z) -> one uncompressed CanonicalSerialize record (host arithmetic),
+ * comparable byte-for-byte with the harness's `arkworks_results.bin` entries. */
+RustError mi355_msm_point_to_serialized(int curve, const void* projective, void* out_record);
+
 /* `batches` MSMs over the SAME bases: scalars holds batches * npoints entries, out receives `batches`
  * projective images (P1A 6block/src/lib.rs:85-109: batch_size = scalars.len() / points.len()).
  * npoints may be smaller than the number of uploaded bases (prefix). */

@@ -244,6 +244,18 @@ class Curve:
             return self._enc_f(one) + self._enc_f(one) + bytes(self.coord_bytes)
         return self._enc_f(P[0]) + self._enc_f(P[1]) + self._enc_f(one)
 
+    def encode_serialized(self, P) -> bytes:
+        """arkworks CanonicalSerialize uncompressed record: x | y little-endian normal form, SWFlags in the last byte's
+        top bits (infinity = 0x40; P1B nickray driver/algebra/serialize/src/flags.rs:107-134)."""
+        cb = self.coord_bytes
+        if P is None:
+            return bytes(2 * cb - 1) + b"\x40"
+        def enc(v):
+            if self.ext == 1:
+                return v.to_bytes(48, "little")
+            return v.c0.to_bytes(48, "little") + v.c1.to_bytes(48, "little")
+        return enc(P[0]) + enc(P[1])
+
     def decode_projective(self, b: bytes):
         """Jacobian (X, Y, Z) image -> affine model point (x = X/Z^2, y = Y/Z^3; ARK :1093-1115)."""
         cb = self.coord_bytes
