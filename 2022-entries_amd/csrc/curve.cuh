@@ -172,8 +172,7 @@ MSM_HD void fe_inv(Fe& r, const Fe& a, const Modulus<F>& md) {
   Fe acc;
   fe_set(acc, F::ONE);
   bool started = false;
-#pragma unroll
-  for (int i = NL - 1; i >= 0; i--) {
+  for (int i = NL - 1; i >= 0; i--) {   // (not unrolled on purpose: 14 x 28 square-and-multiply steps)
     const uint32_t e = pm2_limb<F>(i);
 #pragma unroll 1
     for (int b = LB - 1; b >= 0; b--) {

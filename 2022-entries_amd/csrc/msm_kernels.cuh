@@ -98,26 +98,39 @@ __global__ void __launch_bounds__(256, E::ACC_WAVES) k_accumulate(const uint32_t
   typename E::Md md;
   out.slot_keys[2 * (size_t)t] = KEY_NONE;
   out.slot_keys[2 * (size_t)t + 1] = KEY_NONE;
-  const uint64_t beg = (uint64_t)t * K;
-  const uint64_t end = (beg + K < n_entries) ? beg + K : n_entries;
-  if (beg >= end) return;
+  // 32-bit positions: a chunk never has 2^32 entries (the engine checks), and every VGPR counts in this kernel
+  const uint64_t beg64 = (uint64_t)t * K;
+  if (beg64 >= n_entries) return;
+  const uint32_t beg = (uint32_t)beg64;
+  const uint32_t end = (n_entries - beg > K) ? beg + K : n_entries;
 
-  uint32_t key_n = keys[beg], val_n = vals[beg];
-  AffineDevT<typename E::T> p_n;
-  if (key_n != sentinel) p_n = bases[val_n & IDX_MASK];
+  // Software pipeline: entry indices run TWO iterations ahead and the base gather ONE iteration ahead, so the gather
+  // address never waits on an index load (a dependent load pair would park the wave for ~1 us per add).
+  uint32_t key_c = keys[beg], val_c = vals[beg];
+  uint32_t key_n = sentinel, val_n = 0;
+  if (end - beg > 1) {
+    key_n = keys[beg + 1];
+    val_n = vals[beg + 1];
+  }
+  AffineDevT<typename E::T> p_c;
+  if (key_c != sentinel) p_c = bases[val_c & IDX_MASK];
 
   uint32_t cur = KEY_NONE;
   bool first = true, fresh = true;
   XyzzT<typename E::T> acc;
   xyzz_set_inf<E>(acc);
-  for (uint64_t e = beg; e < end; e++) {
-    const uint32_t key = key_n, val = val_n;
+  for (uint32_t e = beg; e < end; e++) {
+    const uint32_t key = key_c, val = val_c;
     if (key == sentinel) break;  // sorted: nothing but sentinels from here on
-    const AffineT<typename E::T> p = p_n.p;
-    if (e + 1 < end) {
-      key_n = keys[e + 1];
-      val_n = vals[e + 1];
-      if (key_n != sentinel) p_n = bases[val_n & IDX_MASK];
+    const AffineT<typename E::T> p = p_c.p;
+    key_c = key_n;
+    val_c = val_n;
+    if (end - e > 1 && key_c != sentinel) p_c = bases[val_c & IDX_MASK];
+    if (end - e > 2) {
+      key_n = keys[e + 2];
+      val_n = vals[e + 2];
+    } else {
+      key_n = sentinel;
     }
     if (key != cur) {
       if (cur != KEY_NONE) {
@@ -176,7 +189,7 @@ __global__ void __launch_bounds__(256) k_segreduce(const XyzzDevT<typename E::T>
 // so that V = sum_t A'_t + sum_t t * X'_t -- the same problem, L times smaller.  When one chunk is
 // left, V = A'_0.  Running sums walk the chunk from the top: run += X_j; wsum += run.
 template <class E, bool FIRST>
-__global__ void __launch_bounds__(256) k_bucket_reduce(const XyzzDevT<typename E::T>* __restrict__ in_a,
+__global__ void __launch_bounds__(256, E::ACC_WAVES) k_bucket_reduce(const XyzzDevT<typename E::T>* __restrict__ in_a,
                                                        const XyzzDevT<typename E::T>* __restrict__ in_x,
                                                        uint32_t n_per_win, uint32_t logL, uint32_t chunks_per_win,
                                                        uint32_t windows, XyzzDevT<typename E::T>* __restrict__ out_a,
