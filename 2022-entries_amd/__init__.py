@@ -16,6 +16,7 @@ from .msm import (  # noqa: F401
     load_library,
     multi_scalar_mult,
     multi_scalar_mult_init,
+    plan,
     msm,
 )
 from .dist import all_gather_partials, shard_bounds, sharded_msm  # noqa: F401,E402

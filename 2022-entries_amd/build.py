@@ -44,7 +44,7 @@ def build_engine(force: bool = False) -> str:
     every field multiply is fully unrolled -- so they are compiled in parallel), then one link into libmi355msm.so."""
     out = os.path.join(PKG, "libmi355msm.so")
     headers = [f for f in glob.glob(os.path.join(CSRC, "*")) if not f.endswith(".hip") and os.path.isfile(f)]
-    headers += glob.glob(os.path.join(ROOT, "include", "*.h"))
+    abi_headers = glob.glob(os.path.join(ROOT, "include", "*.h"))   # only the engine unit includes the C ABI header
     objdir = os.path.join(PKG, "build")
     os.makedirs(objdir, exist_ok=True)
     cc = hipcc()
@@ -53,7 +53,7 @@ def build_engine(force: bool = False) -> str:
         src = os.path.join(CSRC, unit)
         obj = os.path.join(objdir, unit.replace(".hip", ".o"))
         objs.append(obj)
-        if force or _newer(obj, headers + [src]):
+        if force or _newer(obj, headers + [src] + (abi_headers if unit == "msm_engine.hip" else [])):
             cmd = [cc, "--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-c", src, "-o", obj]
             print("+", " ".join(cmd), flush=True)
             jobs.append((unit, subprocess.Popen(cmd)))

@@ -403,7 +403,6 @@ void run_device(mi355_msm_ctx* ctx, void* out, const void* d_scalars, size_t n, 
   if (!out) bad_arg("null output pointer");
   memset(ctx->last_ms, 0, sizeof ctx->last_ms);
   memset(ctx->last_info, 0, sizeof ctx->last_info);
-  if (!st) st = ctx->own_stream;
   with_curve(ctx->curve, [&]<class C>() { run_device_t<C>(ctx, (uint8_t*)out, (const uint32_t*)d_scalars, n, batches, st); });
 }
 
@@ -631,6 +630,53 @@ RustError mi355_msm_generate_points(int curve, uint64_t seed, size_t distinct, s
     if (!known_curve(curve)) bad_arg("unknown curve id %d", curve);
     if (stride < 2 * coord_bytes(curve) + 1) bad_arg("affine stride %zu too small", stride);
     with_curve(curve, [&]<class C>() { generate_points<C>(seed, distinct, npoints, (uint8_t*)out, stride); });
+  });
+}
+
+RustError mi355_msm_plan(int curve, size_t npoints, int precompute, const long* options, uint64_t* out) {
+  return guarded([&] {
+    if (!known_curve(curve)) bad_arg("unknown curve id %d", curve);
+    if (!out) bad_arg("null output");
+    mi355_msm_ctx tmp;   // never touches the device: only the planning arithmetic
+    tmp.curve = curve;
+    if (options) {
+      tmp.opt_window_bits = options[0];
+      tmp.opt_lane_entries = options[1];
+      tmp.opt_seg_entries = options[2];
+    }
+    if (tmp.opt_window_bits && (tmp.opt_window_bits < 2 || tmp.opt_window_bits > 24)) bad_arg("window_bits out of range");
+    if (tmp.opt_seg_entries && tmp.opt_seg_entries < 4) bad_arg("seg_entries out of range");
+    if (precompute)
+      tmp.pre_c = tmp.opt_window_bits ? (uint32_t)tmp.opt_window_bits : (uint32_t)choose_window_bits(npoints, tmp.scalar_bits(), true);
+    const Plan p = tmp.plan(npoints);
+    // fragment-merge levels: n slots -> 2*ceil(n/segK) until one lane is left
+    uint64_t merge_levels = 0;
+    if (p.nlanes > 1) {
+      uint32_t n_in = 2 * p.nlanes;
+      for (;;) {
+        uint32_t nl = ceil_div(n_in, p.segK);
+        merge_levels++;
+        if (nl == 1) break;
+        if (2 * (uint64_t)nl >= n_in) bad_arg("fragment merge would not shrink");
+        n_in = 2 * nl;
+        if (merge_levels > 64) bad_arg("fragment merge does not terminate");
+      }
+    }
+    uint64_t reduce_levels = 1;
+    for (uint32_t chunks = p.T0; chunks > 1; chunks = ceil_div(chunks, 1u << p.logL)) reduce_levels++;
+    const uint64_t el = (curve == MI355_BLS12_377_G2) ? 2 : 1;
+    out[0] = p.c;
+    out[1] = p.windows;
+    out[2] = p.bucket_windows;
+    out[3] = p.entries;
+    out[4] = p.K;
+    out[5] = p.nlanes;
+    out[6] = merge_levels;
+    out[7] = reduce_levels;
+    out[8] = p.keybits;
+    // device bytes of the per-run work buffers (keys/vals x2, buckets, slots x2, reduce x4)
+    out[9] = p.entries * 16 + (uint64_t)p.bucket_windows * p.half * 224 * el + 2 * (2ull * p.nlanes) * (224 * el + 4) +
+             4ull * p.bucket_windows * p.T0 * 224 * el;
   });
 }
 

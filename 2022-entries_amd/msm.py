@@ -90,6 +90,7 @@ def load_library() -> ctypes.CDLL:
         "mi355_msm": [ci, vp, vp, sz, vp, sz],
         "mi355_msm_fold": [ci, vp, vp, sz],
         "mi355_msm_generate_points": [ci, ctypes.c_uint64, sz, sz, vp, sz],
+        "mi355_msm_plan": [ci, sz, ci, ctypes.POINTER(ctypes.c_long), ctypes.POINTER(ctypes.c_uint64)],
         "mi355_msm_set_bases_serialized": [vp, vp, sz],
         "mi355_msm_point_to_serialized": [ci, vp, vp],
     }
@@ -304,3 +305,15 @@ def generate_points(npoints: int, distinct: int = 1 << 15, seed: int = 0x5A50524
     out = np.zeros((npoints, stride), dtype=np.uint8)
     _check(lib.mi355_msm_generate_points(_curve_id(curve), seed, distinct, npoints, out.ctypes.data, stride))
     return out
+
+
+def plan(npoints: int, curve="bls12_377_g1", precompute: bool = False, window_bits: int = 0, lane_entries: int = 0,
+         seg_entries: int = 0) -> dict:
+    """The engine's execution plan for an MSM of ``npoints`` pairs (host arithmetic only; works without a GPU)."""
+    lib = load_library()
+    opts = (ctypes.c_long * 3)(window_bits, lane_entries, seg_entries)
+    out = (ctypes.c_uint64 * 10)()
+    _check(lib.mi355_msm_plan(_curve_id(curve), npoints, 1 if precompute else 0, opts, out))
+    names = ("window_bits", "windows", "bucket_windows", "entries", "lane_entries", "lanes", "merge_launches", "reduce_launches",
+             "key_bits", "work_bytes")
+    return {k: int(out[i]) for i, k in enumerate(names)}

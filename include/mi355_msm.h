@@ -89,8 +89,8 @@ RustError mi355_msm_point_to_serialized(int curve, const void* projective, void*
  * projective images (P1A 6block/src/lib.rs:85-109: batch_size = scalars.len() / points.len()).
  * npoints may be smaller than the number of uploaded bases (prefix). */
 RustError mi355_msm_run(mi355_msm_ctx* ctx, void* out_projective, const void* scalars, size_t npoints, size_t batches);
-/* Scalars already in DEVICE memory; `stream` is a hipStream_t (NULL = the context's own stream) on which the
- * scalars are ready and on which all work is enqueued.  `out_projective` is HOST memory; the call returns
+/* Scalars already in DEVICE memory; `stream` is the hipStream_t on which the scalars become ready and on which all work is
+ * enqueued (NULL = the HIP default stream, i.e. ordered after whatever a framework's default stream produced).  `out_projective` is HOST memory; the call returns
  * after the result is written (one stream synchronisation per batch chunk). */
 RustError mi355_msm_run_device(mi355_msm_ctx* ctx, void* out_projective, const void* d_scalars, size_t npoints,
                                size_t batches, void* stream);
@@ -126,6 +126,12 @@ RustError mi355_msm_fold(int curve, void* out_projective, const void* projective
  * HOST memory and replicated by doubling the vector up to `npoints`.  Host arithmetic; no device needed. */
 RustError mi355_msm_generate_points(int curve, uint64_t seed, size_t distinct, size_t npoints, void* out_affine,
                                     size_t stride);
+
+/* The execution plan the engine would use for an MSM of `npoints` pairs (pure host arithmetic, no device): out[0..9] =
+ * window bits, digit windows, windows owning buckets (1 with precompute), sorted entries, entries per lane, lanes,
+ * fragment-merge launches, bucket-reduce launches, sort key bits, bytes of per-run device work buffers.
+ * `options` may be NULL or {window_bits, lane_entries, seg_entries} (0 = automatic). */
+RustError mi355_msm_plan(int curve, size_t npoints, int precompute, const long* options, uint64_t* out);
 
 /* Library/ABI version and the gfx target the kernels were built for ("gfx950"). */
 const char* mi355_msm_version(void);

@@ -96,3 +96,30 @@ def test_python_mirror_argument_checks(ea):
         lo, hi = ea.shard_bounds(1 << 20, 8, r)
         covered.append((lo, hi))
     assert covered[0][0] == 0 and covered[-1][1] == 1 << 20 and all(a[1] == b[0] for a, b in zip(covered, covered[1:]))
+
+
+def test_execution_plan_is_sane_and_terminates(ea):
+    """mi355_msm_plan (host arithmetic): for every size class and every tuning knob the fragment merge shrinks to one lane,
+    windows cover 256-bit scalars plus the signed-digit carry, and sort entries stay below 2^32."""
+    for curve in ("bls12_377_g1", "bls12_381_g1", "bls12_377_g2"):
+        for npow in (0, 1, 5, 10, 16, 20, 24, 26):
+            for pre in (False, True):
+                p = ea.plan(1 << npow, curve, precompute=pre)
+                assert p["window_bits"] * p["windows"] >= 257
+                assert p["entries"] == p["windows"] << npow and p["entries"] < 1 << 32
+                assert p["bucket_windows"] == (1 if pre else p["windows"])
+                assert p["lanes"] * p["lane_entries"] >= p["entries"]
+                assert 1 <= p["reduce_launches"] <= 12 and p["merge_launches"] <= 40
+                assert (p["windows"] << (p["window_bits"] - 1) if not pre else 1 << (p["window_bits"] - 1)) < 1 << p["key_bits"]
+    # BASELINE.json sizes: the canonical 2^26 G1 problem fits comfortably in one MI355X (288 GB)
+    p = ea.plan(1 << 26)
+    assert p["window_bits"] in (20, 21, 22) and p["work_bytes"] < 40 << 30
+    assert ea.plan(1 << 26, precompute=True)["window_bits"] in (22, 23, 24)
+    for seg in (4, 5, 7, 64, 4096):
+        for k in (1, 3, 4, 1000):
+            for n in (1, 2, 3, 1000, 12345, 1 << 20):
+                assert ea.plan(n, lane_entries=k, seg_entries=seg)["merge_launches"] <= 64
+    with pytest.raises(ea.MsmError):
+        ea.plan(100, seg_entries=2)
+    with pytest.raises(ea.MsmError):
+        ea.plan(100, window_bits=99)

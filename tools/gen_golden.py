@@ -102,6 +102,10 @@ def main():
     cases.append(case("fpga_edge2", c, [m.EDGE_P, m.EDGE_T, q, m.EDGE_T], [rmont] * 4,
                       "P1B msm_unit_tests.rs:83-133: three points summing to infinity plus T"))
     cases.append(case("fpga_edge5", c, [c.generator(), m.EDGE_P], [1, 2], "P1B msm_unit_tests.rs:246+: G + 2*P"))
+    g = c.generator()
+    cases.append(case("trivial_inputs", c, [g] * 64, [1] + [0] * 63,
+                      "P1B test_fpga_harness/src/util.rs:78-98 TEST_TRIVIAL_INPUTS: all bases = G, scalar 1 then zeros -> G"))
+    assert cases[-1]["expected"] == c.encode_projective_normalized(g).hex()
     pts = m.random_points(c, 64, rng, 16)
     pts[16], pts[31], pts[47], pts[63] = m.EDGE_P, m.EDGE_T, m.EDGE_P_NEG, m.EDGE_T
     cases.append(case("fpga_edge4_boundaries", c, pts, m.random_scalars(c, 64, rng),
