@@ -15,6 +15,7 @@
 #include <string.h>
 
 #include <rocprim/rocprim.hpp>
+#include <functional>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -130,6 +131,8 @@ struct mi355_msm_ctx {
   int curve = 0;
   int device = 0;
   hipStream_t own_stream = nullptr;
+  hipStream_t copy_stream = nullptr;   // H2D of the next scalar batch while the current one computes
+  hipEvent_t copy_ev[2] = {};
   size_t nbases = 0;
   DevBuf bases, inf;
   DevBuf scalars, keys[2], vals[2], sort_tmp, buckets, slots[2], slot_keys[2], red_a[2], red_x[2];
@@ -261,7 +264,7 @@ void set_bases_device(mi355_msm_ctx* ctx, const void* d_affine, size_t n, size_t
 // One chunk of one batch: device scalars [0, n) against bases [base0, base0 + n).  Leaves the folded chunk sum in `out`.
 template <class C>
 void run_chunk(mi355_msm_ctx* ctx, const uint32_t* d_scalars, size_t base0, size_t n, hipStream_t st,
-               XyzzT<typename C::E::T>& out) {
+               XyzzT<typename C::E::T>& out, const std::function<void()>* while_gpu_busy = nullptr) {
   using E = typename C::E;
   using El = typename E::T;
   using XyzzDev = XyzzDevT<El>;
@@ -353,6 +356,8 @@ void run_chunk(mi355_msm_ctx* ctx, const uint32_t* d_scalars, size_t base0, size
   HIP_OK(hipEventRecord(ctx->ev[5], st));
   HIP_OK(hipMemcpyAsync(ctx->pinned, ctx->red_a[rb].p, p.bucket_windows * sizeof(XyzzDev), hipMemcpyDeviceToHost, st));
   HIP_OK(hipEventRecord(ctx->ev[6], st));
+  // everything for this chunk is enqueued: host work that should hide behind it (the next batch's H2D copy) goes here
+  if (while_gpu_busy) (*while_gpu_busy)();
   HIP_OK(hipStreamSynchronize(st));
 
   typename E::Md md;
@@ -377,33 +382,55 @@ void run_chunk(mi355_msm_ctx* ctx, const uint32_t* d_scalars, size_t base0, size
   ctx->last_info[5] = p.nlanes;
 }
 
+// Streams the scalar batches of a host-pointer run: batch b+1 is copied while batch b computes
+// (the reference's double-buffered batches, P1A 6block/cuda/pippenger_inf.cu:110-160; CMB MSM.cu:419-505).
+struct HostBatches {
+  const uint8_t* host;
+  uint8_t* dev;
+  size_t batch_bytes;
+  hipStream_t copy_stream;
+  hipEvent_t ready[2];
+  void copy(size_t b) const {
+    HIP_OK(hipMemcpyAsync(dev + b * batch_bytes, host + b * batch_bytes, batch_bytes, hipMemcpyHostToDevice, copy_stream));
+    HIP_OK(hipEventRecord(ready[b & 1], copy_stream));
+  }
+};
+
 template <class C>
-void run_device_t(mi355_msm_ctx* ctx, uint8_t* out, const uint32_t* d_scalars, size_t n, size_t batches, hipStream_t st) {
+void run_device_t(mi355_msm_ctx* ctx, uint8_t* out, const uint32_t* d_scalars, size_t n, size_t batches, hipStream_t st,
+                  const HostBatches* hb) {
   using E = typename C::E;
   using Xyzz = XyzzT<typename E::T>;
   typename E::Md md;
   const size_t max_chunk = ctx->opt_max_chunk ? (size_t)ctx->opt_max_chunk : ((size_t)1 << 26);
   const size_t out_bytes = 3 * 4 * E::WORDS;
+  if (hb && batches && n) hb->copy(0);
   for (size_t b = 0; b < batches; b++) {
     Xyzz total;
     xyzz_set_inf<E>(total);
+    if (hb && n) HIP_OK(hipStreamWaitEvent(st, hb->ready[b & 1], 0));
+    const std::function<void()> prefetch = [&] {
+      if (hb && b + 1 < batches) hb->copy(b + 1);
+    };
     for (size_t off = 0; off < n; off += max_chunk) {
       size_t cn = std::min(max_chunk, n - off);
+      const bool last = off + cn >= n;
       Xyzz part;
-      run_chunk<C>(ctx, d_scalars + (b * n + off) * 8, off, cn, st, part);
+      run_chunk<C>(ctx, d_scalars + (b * n + off) * 8, off, cn, st, part, last ? &prefetch : nullptr);
       xyzz_add<E>(total, part, md);
     }
     xyzz_to_projective_abi<E>(out + b * out_bytes, total, md);
   }
 }
 
-void run_device(mi355_msm_ctx* ctx, void* out, const void* d_scalars, size_t n, size_t batches, hipStream_t st) {
+void run_device(mi355_msm_ctx* ctx, void* out, const void* d_scalars, size_t n, size_t batches, hipStream_t st,
+                const HostBatches* hb = nullptr) {
   ensure_device(ctx);
   if (n > ctx->nbases) bad_arg("npoints %zu exceeds the %zu uploaded bases", n, ctx->nbases);
   if (!out) bad_arg("null output pointer");
   memset(ctx->last_ms, 0, sizeof ctx->last_ms);
   memset(ctx->last_info, 0, sizeof ctx->last_info);
-  with_curve(ctx->curve, [&]<class C>() { run_device_t<C>(ctx, (uint8_t*)out, (const uint32_t*)d_scalars, n, batches, st); });
+  with_curve(ctx->curve, [&]<class C>() { run_device_t<C>(ctx, (uint8_t*)out, (const uint32_t*)d_scalars, n, batches, st, hb); });
 }
 
 template <class C>
@@ -459,6 +486,9 @@ RustError mi355_msm_destroy(mi355_msm_ctx* ctx) {
     for (auto& ev : ctx->ev)
       if (ev) (void)hipEventDestroy(ev);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    for (auto& ev : ctx->copy_ev)
+      if (ev) (void)hipEventDestroy(ev);
+    if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     delete ctx;
   });
 }
@@ -555,8 +585,12 @@ RustError mi355_msm_run(mi355_msm_ctx* ctx, void* out, const void* scalars, size
     ensure_device(ctx);
     size_t bytes = npoints * batches * 32;
     ctx->scalars.reserve(bytes ? bytes : 32);
-    if (bytes) HIP_OK(hipMemcpyAsync(ctx->scalars.p, scalars, bytes, hipMemcpyHostToDevice, ctx->own_stream));
-    run_device(ctx, out, ctx->scalars.p, npoints, batches, ctx->own_stream);
+    if (!ctx->copy_stream) {
+      HIP_OK(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+      for (auto& ev : ctx->copy_ev) HIP_OK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    }
+    HostBatches hb{(const uint8_t*)scalars, ctx->scalars.as<uint8_t>(), npoints * 32, ctx->copy_stream, {ctx->copy_ev[0], ctx->copy_ev[1]}};
+    run_device(ctx, out, ctx->scalars.p, npoints, batches, ctx->own_stream, &hb);
   });
 }
 
