@@ -100,14 +100,14 @@ inline uint32_t ilog2_floor(uint64_t v) { uint32_t r = 0; while (v >>= 1) r++; r
 // Window size.  Cost model in field-multiply units: one mixed add (10) per non-zero digit, ~50 per bucket for the
 // bucket->window reduction (measured: 0.79 ns/bucket vs 0.15 ns/add).  Canonical scalars have `scalar_bits` bits, so the
 // top window is only partly populated: with `rem` significant bits left it behaves like a full window, with none it
-// only ever receives the signed-digit carry (~15 % of scalars).  Buckets exist for all ceil(257/c) windows (any 256-bit
+// only ever receives the signed-digit carry (about half of the scalars).  Buckets exist for all ceil(257/c) windows (any 256-bit
 // scalar is legal), or for ONE window when precomputed tables let all digits share a bucket set.
 int choose_window_bits(size_t n, int scalar_bits, bool shared_buckets) {
   int best = 2;
   double best_cost = 1e300;
   for (int c = 2; c <= (shared_buckets ? 24 : 23); c++) {
     const int full = scalar_bits / c, rem = scalar_bits - full * c;
-    const double eff = full + (rem >= 2 ? 1.0 : 0.15);
+    const double eff = full + (rem >= 2 ? 1.0 : 0.55);
     const double alloc = shared_buckets ? 1.0 : (double)((257 + c - 1) / c);
     const double cost = eff * (double)n * 10.0 + alloc * (double)(1ull << (c - 1)) * 50.0;
     if (cost < best_cost) { best_cost = cost; best = c; }

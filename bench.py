@@ -71,6 +71,8 @@ def main():
     ap.add_argument("--curve", default="bls12_377_g1", choices=["bls12_377_g1", "bls12_381_g1", "bls12_377_g2"])
     ap.add_argument("--cpu-sample-pow", type=int, default=24, help="log2 pairs of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--precompute", type=int, default=0, help="1 = context with precomputed 2^(c w) P tables (row f1; init untimed)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend for --gpus > 1 (nccl = RCCL over xGMI; gloo only to rehearse the multi-rank path on one GPU)")
     ap.add_argument("--window-bits", type=int, default=0)
     ap.add_argument("--lane-entries", type=int, default=0)
     args = ap.parse_args()
@@ -89,11 +91,17 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the MSM path has no CPU fallback")
+    if args.backend == "gloo":
+        local_rank %= torch.cuda.device_count()      # rehearsal: several ranks may share one GPU
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=device)
+        else:
+            dist.init_process_group(backend="gloo")
+    coll_device = device if args.backend == "nccl" else None
 
     cid = ea.CURVE_IDS[args.curve]
     n = 1 << args.npow
@@ -120,7 +128,7 @@ def main():
     def step():
         partial = ctx.run(scalars)[0]
         if world > 1:
-            return ea.fold_partials(ea.all_gather_partials(partial, device=device), args.curve)
+            return ea.fold_partials(ea.all_gather_partials(partial, device=coll_device), args.curve)
         return partial
 
     def fence():
@@ -144,7 +152,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
