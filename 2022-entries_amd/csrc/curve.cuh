@@ -53,6 +53,7 @@ struct FpEl {
   // ABI images: 12 u32 words per coordinate (x*2^384 mod p, canonical)
   static constexpr int WORDS = 12;
   static constexpr int ACC_WAVES = 2;   // k_accumulate: <= 256 VGPRs, two waves per SIMD saturate VALU issue
+  static constexpr bool PREFETCH_BASE = true;
   static MSM_HD void from_abi(T& r, const uint32_t* w, const Md& md) { fe_from_abi<F>(r, w, md); }
   static MSM_HD void to_abi(uint32_t* w, const T& a, const Md& md) { fe_to_abi<F>(w, a, md); }
   static MSM_HD void reduce(T& r) { fe_reduce<F>(r); }
@@ -128,6 +129,7 @@ struct Fp2El {
   // ABI images: c0 | c1, 12 u32 words each (arkworks QuadExtField { c0, c1 })
   static constexpr int WORDS = 24;
   static constexpr int ACC_WAVES = 1;   // an Fp2 XYZZ accumulator alone is 112 VGPRs: take the whole 512-entry file
+  static constexpr bool PREFETCH_BASE = false;
   static MSM_HD void from_abi(T& r, const uint32_t* w, const Md& md) {
     fe_from_abi<F>(r.c0, w, md);
     fe_from_abi<F>(r.c1, w + 12, md);

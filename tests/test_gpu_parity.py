@@ -210,6 +210,42 @@ def test_prefix_run_and_errors(ea, oracle, torch_cuda):
     ctx.close()
 
 
+def test_randomized_sizes_and_knobs(ea, oracle, torch_cuda):
+    """Fuzz: random sizes, curves, scalar shapes and tuning knobs against the CPU oracle (seeded, 40 cases)."""
+    rng = random.Random(20260929)
+    for case in range(40):
+        cid, curve = CURVES[rng.randrange(2)]
+        n = rng.choice([1, 2, 3, 17, 63, 64, 65, 255, 1000, 4095, 4097, 20000])
+        bases = ea.generate_points(n, distinct=rng.choice([1, 2, 7, 100, n]), seed=case, curve=curve.name)
+        for _ in range(rng.randrange(3)):
+            bases[rng.randrange(n), 96] = 1                       # sprinkle infinity bases
+        kind = rng.randrange(4)
+        sc = rand_scalars_np(cid, n, 1000 + case)
+        if kind == 1:
+            sc[:, 4:] = 0                                         # 32-bit scalars: most windows empty
+        elif kind == 2:
+            sc[rng.randrange(n)] = 0
+            sc[::3] = sc[0]                                       # repeated scalar: hot buckets
+        elif kind == 3:
+            sc[:, :16] = 0                                        # only high limbs set
+        ctx = ea.MultiScalarMultContext(curve.name)
+        pre = rng.random() < 0.3
+        if pre:
+            ctx.set_option("precompute", 1)
+        if rng.random() < 0.6:
+            ctx.set_option("window_bits", rng.randrange(2, 17))
+        ctx.set_bases(bases)
+        if rng.random() < 0.5:
+            ctx.set_option("lane_entries", rng.choice([1, 2, 4, 8, 33, 500]))
+        if rng.random() < 0.4:
+            ctx.set_option("seg_entries", rng.choice([4, 5, 9, 100]))
+        if rng.random() < 0.3:
+            ctx.set_option("max_chunk", rng.choice([1, 7, 1000, 5000]))
+        got = ctx.run(sc)[0]
+        ctx.close()
+        assert got == oracle_msm_np(oracle, cid, bases, sc, n), (case, curve.name, n, kind, pre)
+
+
 # ---- G2 (BASELINE.json configs[4]): Fq2 coordinates through the same kernels ------------------------------------
 
 def _oracle_g2(oracle, bases_np, scalars_np, n):
