@@ -183,7 +183,8 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "u32 limbs (radix-2^28 Montgomery, 64-bit MAD accumulate)",
+            "dtype": "u32",
+            "dtype_detail": "14 x 28-bit limbs in u32 lanes, Montgomery radix 2^392, products accumulated in u64 (v_mad_u64_u32)",
             "data": "synthetic: 2^15 distinct subgroup points replicated (reference generator shape), uniform scalars < r",
             "config": {"workload": f"{args.curve} MSM, 2^{args.npow} pairs per GPU, bases+scalars resident in HBM",
                        "pairs_per_gpu": n, "window_bits": tm["window_bits"], "windows": tm["windows"],
