@@ -391,5 +391,16 @@ def test_full_size_properties(ea, oracle, torch_cuda, cid, curve, npow):
         oracle, cid, np.ascontiguousarray(np.tile(tile, (sample >> 15, 1))), sc, sample)
     # (5) idempotence / determinism
     assert ctx.run(as_bytes(k1))[0] == r1
+    # (6) internal chunking at scale: the same MSM through chunks of 2^(npow-1) - 12345 pairs (three chunks, large base offsets)
+    ctx.set_option("max_chunk", (n // 2) - 12345)
+    assert ctx.run(as_bytes(k1))[0] == r1
+    ctx.set_option("max_chunk", 0)
+    # (7) a context with precomputed tables gives the same point
+    if npow <= 24 or cid == 0:
+        ctx_pre = ea.MultiScalarMultContext(curve.name)
+        ctx_pre.set_option("precompute", 1)
+        ctx_pre.set_bases(bases)
+        assert ctx_pre.run(as_bytes(k1))[0] == r1
+        ctx_pre.close()
     ctx.close()
     ctx_hi.close()
