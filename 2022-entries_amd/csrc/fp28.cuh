@@ -83,12 +83,100 @@ MSM_HD void fe_zero(Fe& r) {
   for (int i = 0; i < NL; i++) r.v[i] = 0;
 }
 
+// col += sum_{i<n} x[i]*y[i] as ONE uninterrupted chain of v_mad_u64_u32 (n <= 14, a compile-time constant after
+// unrolling).  Written as inline assembly on the device because hipcc otherwise splits such a chain every few terms
+// with a v_lshl_add_u64/v_mov pair (it reassociates the 64-bit sum): 34 extra VALU instructions per multiplication,
+// 4-5 % of its issue time (tools/ubench_mul.hip).  YS = true: the y operands are wave-uniform (modulus limbs in SGPRs).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MSM_MAD(x, y) "v_mad_u64_u32 %0, vcc, %" #x ", %" #y ", %0\n\t"
+#define MSM_MADS_1 MSM_MAD(1, 2)
+#define MSM_MADS_2 MSM_MADS_1 MSM_MAD(3, 4)
+#define MSM_MADS_3 MSM_MADS_2 MSM_MAD(5, 6)
+#define MSM_MADS_4 MSM_MADS_3 MSM_MAD(7, 8)
+#define MSM_MADS_5 MSM_MADS_4 MSM_MAD(9, 10)
+#define MSM_MADS_6 MSM_MADS_5 MSM_MAD(11, 12)
+#define MSM_MADS_7 MSM_MADS_6 MSM_MAD(13, 14)
+#define MSM_MADS_8 MSM_MADS_7 MSM_MAD(15, 16)
+#define MSM_MADS_9 MSM_MADS_8 MSM_MAD(17, 18)
+#define MSM_MADS_10 MSM_MADS_9 MSM_MAD(19, 20)
+#define MSM_MADS_11 MSM_MADS_10 MSM_MAD(21, 22)
+#define MSM_MADS_12 MSM_MADS_11 MSM_MAD(23, 24)
+#define MSM_MADS_13 MSM_MADS_12 MSM_MAD(25, 26)
+#define MSM_MADS_14 MSM_MADS_13 MSM_MAD(27, 28)
+#define MSM_OPS_1(YC) "v"(x[0]), YC(y[0])
+#define MSM_OPS_2(YC) MSM_OPS_1(YC), "v"(x[1]), YC(y[1])
+#define MSM_OPS_3(YC) MSM_OPS_2(YC), "v"(x[2]), YC(y[2])
+#define MSM_OPS_4(YC) MSM_OPS_3(YC), "v"(x[3]), YC(y[3])
+#define MSM_OPS_5(YC) MSM_OPS_4(YC), "v"(x[4]), YC(y[4])
+#define MSM_OPS_6(YC) MSM_OPS_5(YC), "v"(x[5]), YC(y[5])
+#define MSM_OPS_7(YC) MSM_OPS_6(YC), "v"(x[6]), YC(y[6])
+#define MSM_OPS_8(YC) MSM_OPS_7(YC), "v"(x[7]), YC(y[7])
+#define MSM_OPS_9(YC) MSM_OPS_8(YC), "v"(x[8]), YC(y[8])
+#define MSM_OPS_10(YC) MSM_OPS_9(YC), "v"(x[9]), YC(y[9])
+#define MSM_OPS_11(YC) MSM_OPS_10(YC), "v"(x[10]), YC(y[10])
+#define MSM_OPS_12(YC) MSM_OPS_11(YC), "v"(x[11]), YC(y[11])
+#define MSM_OPS_13(YC) MSM_OPS_12(YC), "v"(x[12]), YC(y[12])
+#define MSM_OPS_14(YC) MSM_OPS_13(YC), "v"(x[13]), YC(y[13])
+#define MSM_CHAIN_CASE(n)                                                    \
+  case n:                                                                    \
+    if (YS)                                                                  \
+      asm(MSM_MADS_##n : "+v"(col) : MSM_OPS_##n("s") : "vcc");              \
+    else                                                                     \
+      asm(MSM_MADS_##n : "+v"(col) : MSM_OPS_##n("v") : "vcc");              \
+    break;
+#endif
+
+template <bool YS>
+MSM_HD void mad_chain(uint64_t& col, const uint32_t (&x)[NL], const uint32_t (&y)[NL], int n) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  switch (n) {
+    MSM_CHAIN_CASE(1)
+    MSM_CHAIN_CASE(2)
+    MSM_CHAIN_CASE(3)
+    MSM_CHAIN_CASE(4)
+    MSM_CHAIN_CASE(5)
+    MSM_CHAIN_CASE(6)
+    MSM_CHAIN_CASE(7)
+    MSM_CHAIN_CASE(8)
+    MSM_CHAIN_CASE(9)
+    MSM_CHAIN_CASE(10)
+    MSM_CHAIN_CASE(11)
+    MSM_CHAIN_CASE(12)
+    MSM_CHAIN_CASE(13)
+    MSM_CHAIN_CASE(14)
+    default:
+      break;
+  }
+#else
+  for (int i = 0; i < n; i++) col += (uint64_t)x[i] * y[i];
+#endif
+}
+
+// The Montgomery step of column k: col += m_k * p_0 (which clears the low limb), then shift the column down.
+// When p = 1 (mod 2^28) -- BLS12-377, whose p - 1 is divisible by 2^46 -- m_k = -col mod 2^28 and p_0 = 1, so
+// (col + m_k) >> 28 = (col + 2^28 - 1) >> 28: one 64-bit add instead of a multiply-add (126 fewer per mixed addition).
+#define MSM_MONT_STEP(F, col, mk, md)                                              \
+  do {                                                                             \
+    if (F::P[0] == 1) {                                                            \
+      MSM_CHECK_COL_ADD(mk);                                                       \
+      MSM_CHECK_COL_END((col) + (mk));                                             \
+      MSM_CHECK((((col) + (mk)) & LMASK) == 0 && (((col) + (mk)) >> LB) == (((col) + LMASK) >> LB)); \
+      (col) = ((col) + LMASK) >> LB;                                               \
+    } else {                                                                       \
+      (col) += (uint64_t)(mk) * (md).p[0];                                         \
+      MSM_CHECK_COL_ADD((unsigned __int128)(mk) * (md).p[0]);                      \
+      MSM_CHECK_COL_END(col);                                                      \
+      MSM_CHECK(((uint32_t)(col) & LMASK) == 0);                                   \
+      (col) >>= LB;                                                                \
+    }                                                                              \
+  } while (0)
+
 // r = a*b*R^-1 (mod p), class M.  Product scanning: column k gathers every a_i*b_j and m_i*p_j with
 // i+j = k in ONE 64-bit accumulator; m_k clears the low 28 bits and the column is shifted down.
 // Bound: limbs < 2^30  =>  14*(2^30)^2 + 14*(2^28)^2 + carry < 2^64.
 template <class F>
 MSM_HD void fe_mul(Fe& r, const Fe& a, const Fe& b, const Modulus<F>& md) {
-  uint32_t m[NL];
+  uint32_t m[NL], xs[NL], ys[NL];
   Fe t;
   uint64_t col = 0;
 #pragma unroll
@@ -100,34 +188,38 @@ MSM_HD void fe_mul(Fe& r, const Fe& a, const Fe& b, const Modulus<F>& md) {
     MSM_CHECK_COL_BEGIN();
 #pragma unroll
     for (int i = 0; i <= k; i++) {
-      col += (uint64_t)a.v[i] * b.v[k - i];
+      xs[i] = a.v[i];
+      ys[i] = b.v[k - i];
       MSM_CHECK_COL_ADD((unsigned __int128)a.v[i] * b.v[k - i]);
     }
+    mad_chain<false>(col, xs, ys, k + 1);
 #pragma unroll
     for (int i = 0; i < k; i++) {
-      col += (uint64_t)m[i] * md.p[k - i];
+      xs[i] = m[i];
+      ys[i] = md.p[k - i];
       MSM_CHECK_COL_ADD((unsigned __int128)m[i] * md.p[k - i]);
     }
+    mad_chain<true>(col, xs, ys, k);
     m[k] = ((uint32_t)col * F::M0) & LMASK;
-    col += (uint64_t)m[k] * md.p[0];
-    MSM_CHECK_COL_ADD((unsigned __int128)m[k] * md.p[0]);
-    MSM_CHECK_COL_END(col);
-    MSM_CHECK(((uint32_t)col & LMASK) == 0);
-    col >>= LB;
+    MSM_MONT_STEP(F, col, m[k], md);
   }
 #pragma unroll
   for (int k = NL; k < 2 * NL - 1; k++) {
     MSM_CHECK_COL_BEGIN();
 #pragma unroll
     for (int i = k - NL + 1; i < NL; i++) {
-      col += (uint64_t)a.v[i] * b.v[k - i];
+      xs[i - (k - NL + 1)] = a.v[i];
+      ys[i - (k - NL + 1)] = b.v[k - i];
       MSM_CHECK_COL_ADD((unsigned __int128)a.v[i] * b.v[k - i]);
     }
+    mad_chain<false>(col, xs, ys, 2 * NL - 1 - k);
 #pragma unroll
     for (int i = k - NL + 1; i < NL; i++) {
-      col += (uint64_t)m[i] * md.p[k - i];
+      xs[i - (k - NL + 1)] = m[i];
+      ys[i - (k - NL + 1)] = md.p[k - i];
       MSM_CHECK_COL_ADD((unsigned __int128)m[i] * md.p[k - i]);
     }
+    mad_chain<true>(col, xs, ys, 2 * NL - 1 - k);
     MSM_CHECK_COL_END(col);
     t.v[k - NL] = (uint32_t)col & LMASK;
     col >>= LB;
@@ -142,7 +234,7 @@ MSM_HD void fe_mul(Fe& r, const Fe& a, const Fe& b, const Modulus<F>& md) {
 // values: a*b + c*d <= 2^10 p^2 as for fe_mul.
 template <class F>
 MSM_HD void fe_mul2(Fe& r, const Fe& a, const Fe& b, const Fe& c, const Fe& d, const Modulus<F>& md) {
-  uint32_t m[NL];
+  uint32_t m[NL], xs[NL], ys[NL];
   Fe t;
   uint64_t col = 0;
 #pragma unroll
@@ -156,35 +248,50 @@ MSM_HD void fe_mul2(Fe& r, const Fe& a, const Fe& b, const Fe& c, const Fe& d, c
     MSM_CHECK_COL_BEGIN();
 #pragma unroll
     for (int i = 0; i <= k; i++) {
-      col += (uint64_t)a.v[i] * b.v[k - i];
-      col += (uint64_t)c.v[i] * d.v[k - i];
+      xs[i] = a.v[i];
+      ys[i] = b.v[k - i];
       MSM_CHECK_COL_ADD((unsigned __int128)a.v[i] * b.v[k - i] + (unsigned __int128)c.v[i] * d.v[k - i]);
     }
+    mad_chain<false>(col, xs, ys, k + 1);
+#pragma unroll
+    for (int i = 0; i <= k; i++) {
+      xs[i] = c.v[i];
+      ys[i] = d.v[k - i];
+    }
+    mad_chain<false>(col, xs, ys, k + 1);
 #pragma unroll
     for (int i = 0; i < k; i++) {
-      col += (uint64_t)m[i] * md.p[k - i];
+      xs[i] = m[i];
+      ys[i] = md.p[k - i];
       MSM_CHECK_COL_ADD((unsigned __int128)m[i] * md.p[k - i]);
     }
+    mad_chain<true>(col, xs, ys, k);
     m[k] = ((uint32_t)col * F::M0) & LMASK;
-    col += (uint64_t)m[k] * md.p[0];
-    MSM_CHECK_COL_ADD((unsigned __int128)m[k] * md.p[0]);
-    MSM_CHECK_COL_END(col);
-    col >>= LB;
+    MSM_MONT_STEP(F, col, m[k], md);
   }
 #pragma unroll
   for (int k = NL; k < 2 * NL - 1; k++) {
     MSM_CHECK_COL_BEGIN();
 #pragma unroll
     for (int i = k - NL + 1; i < NL; i++) {
-      col += (uint64_t)a.v[i] * b.v[k - i];
-      col += (uint64_t)c.v[i] * d.v[k - i];
+      xs[i - (k - NL + 1)] = a.v[i];
+      ys[i - (k - NL + 1)] = b.v[k - i];
       MSM_CHECK_COL_ADD((unsigned __int128)a.v[i] * b.v[k - i] + (unsigned __int128)c.v[i] * d.v[k - i]);
     }
+    mad_chain<false>(col, xs, ys, 2 * NL - 1 - k);
 #pragma unroll
     for (int i = k - NL + 1; i < NL; i++) {
-      col += (uint64_t)m[i] * md.p[k - i];
+      xs[i - (k - NL + 1)] = c.v[i];
+      ys[i - (k - NL + 1)] = d.v[k - i];
+    }
+    mad_chain<false>(col, xs, ys, 2 * NL - 1 - k);
+#pragma unroll
+    for (int i = k - NL + 1; i < NL; i++) {
+      xs[i - (k - NL + 1)] = m[i];
+      ys[i - (k - NL + 1)] = md.p[k - i];
       MSM_CHECK_COL_ADD((unsigned __int128)m[i] * md.p[k - i]);
     }
+    mad_chain<true>(col, xs, ys, 2 * NL - 1 - k);
     MSM_CHECK_COL_END(col);
     t.v[k - NL] = (uint32_t)col & LMASK;
     col >>= LB;
@@ -199,7 +306,7 @@ MSM_HD void fe_mul2(Fe& r, const Fe& a, const Fe& b, const Fe& c, const Fe& d, c
 // Bound: limbs < 2^30  =>  7*2^30*2^31 + 2^60 + 14*(2^28)^2 + carry < 2^64.
 template <class F>
 MSM_HD void fe_sqr(Fe& r, const Fe& a, const Modulus<F>& md) {
-  uint32_t m[NL], a2[NL];
+  uint32_t m[NL], a2[NL], xs[NL], ys[NL];
   Fe t;
   uint64_t col = 0;
 #pragma unroll
@@ -210,43 +317,56 @@ MSM_HD void fe_sqr(Fe& r, const Fe& a, const Modulus<F>& md) {
 #pragma unroll
   for (int k = 0; k < NL; k++) {
     MSM_CHECK_COL_BEGIN();
+    int n = 0;
 #pragma unroll
     for (int i = 0; 2 * i < k; i++) {
-      col += (uint64_t)a.v[i] * a2[k - i];
+      xs[n] = a.v[i];
+      ys[n] = a2[k - i];
+      n++;
       MSM_CHECK_COL_ADD((unsigned __int128)a.v[i] * a2[k - i]);
     }
     if ((k & 1) == 0) {
-      col += (uint64_t)a.v[k / 2] * a.v[k / 2];
+      xs[n] = a.v[k / 2];
+      ys[n] = a.v[k / 2];
+      n++;
       MSM_CHECK_COL_ADD((unsigned __int128)a.v[k / 2] * a.v[k / 2]);
     }
+    mad_chain<false>(col, xs, ys, n);
 #pragma unroll
     for (int i = 0; i < k; i++) {
-      col += (uint64_t)m[i] * md.p[k - i];
+      xs[i] = m[i];
+      ys[i] = md.p[k - i];
       MSM_CHECK_COL_ADD((unsigned __int128)m[i] * md.p[k - i]);
     }
+    mad_chain<true>(col, xs, ys, k);
     m[k] = ((uint32_t)col * F::M0) & LMASK;
-    col += (uint64_t)m[k] * md.p[0];
-    MSM_CHECK_COL_ADD((unsigned __int128)m[k] * md.p[0]);
-    MSM_CHECK_COL_END(col);
-    col >>= LB;
+    MSM_MONT_STEP(F, col, m[k], md);
   }
 #pragma unroll
   for (int k = NL; k < 2 * NL - 1; k++) {
     MSM_CHECK_COL_BEGIN();
+    int n = 0;
 #pragma unroll
     for (int i = k - NL + 1; 2 * i < k; i++) {
-      col += (uint64_t)a.v[i] * a2[k - i];
+      xs[n] = a.v[i];
+      ys[n] = a2[k - i];
+      n++;
       MSM_CHECK_COL_ADD((unsigned __int128)a.v[i] * a2[k - i]);
     }
     if ((k & 1) == 0) {
-      col += (uint64_t)a.v[k / 2] * a.v[k / 2];
+      xs[n] = a.v[k / 2];
+      ys[n] = a.v[k / 2];
+      n++;
       MSM_CHECK_COL_ADD((unsigned __int128)a.v[k / 2] * a.v[k / 2]);
     }
+    mad_chain<false>(col, xs, ys, n);
 #pragma unroll
     for (int i = k - NL + 1; i < NL; i++) {
-      col += (uint64_t)m[i] * md.p[k - i];
+      xs[i - (k - NL + 1)] = m[i];
+      ys[i - (k - NL + 1)] = md.p[k - i];
       MSM_CHECK_COL_ADD((unsigned __int128)m[i] * md.p[k - i]);
     }
+    mad_chain<true>(col, xs, ys, 2 * NL - 1 - k);
     MSM_CHECK_COL_END(col);
     t.v[k - NL] = (uint32_t)col & LMASK;
     col >>= LB;

@@ -113,8 +113,8 @@ __global__ void __launch_bounds__(256, E::ACC_WAVES) k_accumulate(const uint32_t
     val_n = vals[beg + 1];
   }
   // (E::PREFETCH_BASE = false -- G2, whose accumulator alone is 112 VGPRs -- gathers the base at its point of use instead)
-  AffineDevT<typename E::T> p_c;
-  if (E::PREFETCH_BASE && key_c != sentinel) p_c = bases[val_c & IDX_MASK];
+  AffineT<typename E::T> p_c;
+  if (E::PREFETCH_BASE && key_c != sentinel) p_c = bases[val_c & IDX_MASK].p;
 
   uint32_t cur = KEY_NONE;
   bool first = true, fresh = true;
@@ -123,11 +123,11 @@ __global__ void __launch_bounds__(256, E::ACC_WAVES) k_accumulate(const uint32_t
   for (uint32_t e = beg; e < end; e++) {
     const uint32_t key = key_c, val = val_c;
     if (key == sentinel) break;  // sorted: nothing but sentinels from here on
-    if (!E::PREFETCH_BASE) p_c = bases[val & IDX_MASK];
-    const AffineT<typename E::T> p = p_c.p;
+    if (!E::PREFETCH_BASE) p_c = bases[val & IDX_MASK].p;
+    const AffineT<typename E::T> p = p_c;
     key_c = key_n;
     val_c = val_n;
-    if (E::PREFETCH_BASE && end - e > 1 && key_c != sentinel) p_c = bases[val_c & IDX_MASK];
+    if (E::PREFETCH_BASE && end - e > 1 && key_c != sentinel) p_c = bases[val_c & IDX_MASK].p;
     if (end - e > 2) {
       key_n = keys[e + 2];
       val_n = vals[e + 2];

@@ -10,7 +10,7 @@ constexpr uint32_t IDX_MASK = 0x7fffffffu;
 // Device layouts: AoS, 16-byte aligned so one lane's gather/store is a run of dwordx4 accesses.
 //   G1: affine 112 B (2 x 14 limbs), XYZZ 224 B;   G2: affine 224 B, XYZZ 448 B.
 template <class T>
-struct alignas(16) AffineDevT {
+struct alignas(128) AffineDevT {
   AffineT<T> p;
 };
 template <class T>
@@ -19,7 +19,7 @@ struct alignas(16) XyzzDevT {
 };
 using AffineDev = AffineDevT<Fe>;
 using XyzzDev = XyzzDevT<Fe>;
-static_assert(sizeof(AffineDev) == 112 && sizeof(AffineDevT<Fe2>) == 224, "device affine layout");
+static_assert(sizeof(AffineDev) == 128 && sizeof(AffineDevT<Fe2>) == 256, "device affine layout");
 static_assert(sizeof(XyzzDev) == 224 && sizeof(XyzzDevT<Fe2>) == 448, "device xyzz layout");
 
 template <class T>
