@@ -162,6 +162,17 @@ class _Buf:
             self.nbytes = len(b)
 
 
+def _flat_bytes(obj):
+    """1-D byte view of a bytes / numpy / torch input, sliceable by byte offset."""
+    if hasattr(obj, "data_ptr") and hasattr(obj, "is_cuda"):
+        return obj.contiguous().reshape(-1)
+    if hasattr(obj, "__array_interface__"):
+        import numpy as np
+
+        return np.ascontiguousarray(obj).view(np.uint8).reshape(-1)
+    return memoryview(obj if isinstance(obj, (bytes, bytearray)) else bytes(obj))
+
+
 class MultiScalarMultContext:
     """``#[repr(C)] struct MultiScalarMultContext { context: *mut c_void }`` (P1A 6block/src/lib.rs:18-21)."""
 
@@ -280,6 +291,31 @@ class VariableBaseMSM:
         return self.msm(bases, scalars)
 
     msm_bigint = msm
+
+    def msm_chunks(self, bases_stream, scalars_stream, step: int = 1 << 20) -> bytes:
+        """Streaming form (ARK ec/src/msm/variable_base/mod.rs:165-199): ``scalars_stream`` holds ``Fr`` values (Montgomery
+        form, converted on the device like ``into_bigint``) and must not be longer than ``bases_stream``; the LAST
+        ``len(scalars)`` bases are used ("align the streams"), ``step`` pairs at a time, and the partial sums are added.
+        The reference hard-codes step = 2^20; any step gives the same point."""
+        stride = affine_stride(self.curve)
+        bases_stream, scalars_stream = _flat_bytes(bases_stream), _flat_bytes(scalars_stream)
+        nb, ns = len(bases_stream) // stride, len(scalars_stream) // SCALAR_BYTES
+        if ns > nb:
+            raise MsmError(-1, f"msm_chunks: {ns} scalars for {nb} bases (scalars_stream.len() <= bases_stream.len())")
+        if step <= 0:
+            raise MsmError(-1, "msm_chunks: step must be positive")
+        skip = nb - ns
+        ctx = MultiScalarMultContext(self.curve)
+        try:
+            ctx.set_option("scalars_montgomery", 1)
+            partials = []
+            for lo in range(0, ns, step):
+                hi = min(ns, lo + step)
+                ctx.set_bases(bases_stream[(skip + lo) * stride:(skip + hi) * stride])
+                partials.append(ctx.run(scalars_stream[lo * SCALAR_BYTES:hi * SCALAR_BYTES], hi - lo)[0])
+            return fold_partials(partials, self.curve)
+        finally:
+            ctx.close()
 
 
 def fold_partials(partials: Sequence[bytes], curve="bls12_377_g1") -> bytes:

@@ -84,4 +84,26 @@ inline G1Projective msm(const std::vector<G1Affine>& bases, const std::vector<Bi
   return out;
 }
 
+// VariableBaseMSM::msm_chunks (ARK ec/src/msm/variable_base/mod.rs:165-199): `scalars` are Fr values (Montgomery form,
+// converted on the device like into_bigint), must not outnumber the bases, pair up with the LAST scalars.size() bases, and
+// are consumed `step` pairs at a time (the reference hard-codes 2^20); the partial sums are added.
+inline G1Projective msm_chunks(const std::vector<G1Affine>& bases, const std::vector<BigInteger256>& scalars_fr,
+                               size_t step = size_t(1) << 20, int curve = MI355_BLS12_377_G1) {
+  if (scalars_fr.size() > bases.size() || step == 0) throw MsmError(-1, "msm_chunks: scalars_stream.len() <= bases_stream.len()");
+  const size_t ns = scalars_fr.size(), skip = bases.size() - ns;
+  MultiScalarMultContext ctx;
+  check(mi355_msm_create(&ctx.context, curve, -1));
+  check(mi355_msm_set_option(ctx.context, "scalars_montgomery", 1));
+  std::vector<G1Projective> partials;
+  for (size_t lo = 0; lo < ns; lo += step) {
+    const size_t n = ns - lo < step ? ns - lo : step;
+    check(mi355_msm_set_bases(ctx.context, bases.data() + skip + lo, n, sizeof(G1Affine)));
+    partials.emplace_back();
+    check(mi355_msm_run(ctx.context, &partials.back(), scalars_fr.data() + lo, n, 1));
+  }
+  G1Projective out;
+  check(mi355_msm_fold(curve, &out, partials.data(), partials.size()));
+  return out;
+}
+
 }  // namespace mi355

@@ -161,6 +161,27 @@ def test_montgomery_form_scalars(ea, oracle, torch_cuda, cid, curve):
     ctx.close()
 
 
+def test_msm_chunks_streaming(ea, oracle, torch_cuda):
+    """VariableBaseMSM::msm_chunks (ARK ec/src/msm/variable_base/mod.rs:165-199): Fr scalars, the last len(scalars) bases,
+    `step` pairs at a time, partial sums added; any step gives the point msm_bigint gives on the aligned inputs."""
+    cid, curve = 0, m.BLS12_377_G1
+    rng = random.Random(77)
+    nb, ns = 2700, 2500
+    ks = m.random_scalars(curve, ns, rng)
+    ks[0], ks[-1] = 0, curve.r - 1
+    bases = ea.generate_points(nb, distinct=300, seed=8, curve=curve.name)
+    plain = np.frombuffer(m.encode_scalars(ks), dtype=np.uint8).reshape(ns, 32)
+    mont = np.frombuffer(m.encode_scalars([(k << 256) % curve.r for k in ks]), dtype=np.uint8).reshape(ns, 32)
+    exp = oracle_msm_np(oracle, cid, np.ascontiguousarray(bases[nb - ns:]), np.ascontiguousarray(plain), ns)
+    v = ea.VariableBaseMSM(curve.name)
+    assert v.msm_chunks(bases, mont) == exp                       # one step covers everything
+    assert v.msm_chunks(bases, mont, step=1000) == exp            # 1000 + 1000 + 500
+    assert v.msm_chunks(bases.tobytes(), mont.tobytes(), step=999) == exp
+    assert v.msm_chunks(bases, mont[:0]) == curve.encode_projective_normalized(None)
+    with pytest.raises(ea.MsmError):
+        v.msm_chunks(bases[:10], mont)                            # assert!(scalars_stream.len() <= bases_stream.len())
+
+
 @pytest.mark.parametrize("cid,curve", CURVES)
 def test_precomputed_tables(ea, oracle, golden, torch_cuda, cid, curve):
     """Row f1: a context with precomputed 2^(c w) P tables (all digits share one bucket set) returns the same bytes,

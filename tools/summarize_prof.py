@@ -32,6 +32,17 @@ for f in glob.glob(os.path.join(root, "stats", "**", "*kernel_stats.csv"), recur
         print("%-60s %8d %14.3f %14.4f %6.1f%%" % (k, calls, ns / 1e6, ns / 1e6 / calls, 100 * ns / tot))
 
 print()
+print("== k_accumulate per launch configuration (kernel trace of the same run; grid = lanes) ==")
+for f in glob.glob(os.path.join(root, "stats", "**", "*kernel_trace.csv"), recursive=True):
+    per = defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if "k_accumulate" in r["Kernel_Name"]:
+            per[(short(r["Kernel_Name"]), int(r["Grid_Size_X"]), int(r["VGPR_Count"]), int(r["Scratch_Size"]))].append(
+                (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
+    for (k, grid, vg, scr), v in sorted(per.items()):
+        print("%-22s lanes=%-9d scratch=%-3d launches=%-3d avg_ms=%.3f min=%.3f max=%.3f" % (k, grid, scr, len(v), sum(v) / len(v), min(v), max(v)))
+
+print()
 print("== PMC passes (per-kernel sums over one bench step; FETCH_SIZE/WRITE_SIZE in KiB as reported) ==")
 for d in sorted(glob.glob(os.path.join(root, "pmc_*"))):
     if not os.path.isdir(d):
@@ -44,5 +55,14 @@ for d in sorted(glob.glob(os.path.join(root, "pmc_*"))):
             agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
             disp[k].add(r.get("Dispatch_Id", "0"))
         print("-- %s" % os.path.basename(d))
+        rows = list(csv.DictReader(open(f)))
+        perd = defaultdict(lambda: defaultdict(float))
+        grid = {}
+        for r in rows:
+            if "k_accumulate" in r.get("Kernel_Name", ""):
+                perd[r["Dispatch_Id"]][r["Counter_Name"]] += float(r["Counter_Value"])
+                grid[r["Dispatch_Id"]] = r.get("Grid_Size", "?")
+        for did in sorted(perd, key=int):
+            print("   k_accumulate dispatch %-5s lanes=%-9s %s" % (did, grid[did], "  ".join("%s=%.6g" % kv for kv in sorted(perd[did].items()))))
         for k in sorted(agg, key=lambda k: -max(agg[k].values())):
             print("   %-56s dispatches=%-4d %s" % (k, len(disp[k]), "  ".join("%s=%.6g" % kv for kv in sorted(agg[k].items()))))
