@@ -76,7 +76,11 @@ void run(const char* name, int iters) {
          name, iters, ms[0], muls / ms[0] / 1e6, ms[1], muls / ms[1] / 1e6, ms[1] / ms[0], diff);
 }
 
-int main() {
+int main(int argc, char** argv) {
+  if (argc > 1) {  // one long run (e.g. 300000 iterations = 2 s per arm) for tools/power_probe.sh
+    run<Bls12_377_Fq>("bls12_377 fq", atoi(argv[1]));
+    return 0;
+  }
   for (int it : {2000, 20000, 60000}) run<Bls12_377_Fq>("bls12_377 fq", it);
   run<Bls12_381_Fq>("bls12_381 fq", 20000);
   return 0;
