@@ -132,7 +132,7 @@ struct mi355_msm_ctx {
   int device = 0;
   hipStream_t own_stream = nullptr;
   hipStream_t copy_stream = nullptr;   // H2D of the next scalar batch while the current one computes
-  hipEvent_t copy_ev[2] = {};
+  hipEvent_t copy_ev[3] = {};   // batch parity 0/1 resident, first piece of batch 0 resident
   size_t nbases = 0;
   DevBuf bases, inf;
   DevBuf scalars, keys[2], vals[2], sort_tmp, buckets, slots[2], slot_keys[2], red_a[2], red_x[2];
@@ -383,18 +383,30 @@ void run_chunk(mi355_msm_ctx* ctx, const uint32_t* d_scalars, size_t base0, size
 }
 
 // Streams the scalar batches of a host-pointer run: batch b+1 is copied while batch b computes
-// (the reference's double-buffered batches, P1A 6block/cuda/pippenger_inf.cu:110-160; CMB MSM.cu:419-505).
+// (the reference's double-buffered batches, P1A 6block/cuda/pippenger_inf.cu:110-160; CMB MSM.cu:419-505), and the FIRST
+// batch -- whose copy nothing can hide -- is handed over in two pieces, 1/4 then 3/4, so that the first quarter is already
+// accumulating while the rest crosses PCIe (the reference's quarter-split first copy, CMB MSM.cu:419-434).
 struct HostBatches {
   const uint8_t* host;
   uint8_t* dev;
   size_t batch_bytes;
   hipStream_t copy_stream;
-  hipEvent_t ready[2];
-  void copy(size_t b) const {
-    HIP_OK(hipMemcpyAsync(dev + b * batch_bytes, host + b * batch_bytes, batch_bytes, hipMemcpyHostToDevice, copy_stream));
-    HIP_OK(hipEventRecord(ready[b & 1], copy_stream));
+  hipEvent_t ready[2];   // whole batch b resident: ready[b & 1]
+  hipEvent_t head;       // first piece of batch 0 resident
+  void copy_pairs(size_t b, size_t first, size_t count, hipEvent_t ev) const {
+    HIP_OK(hipMemcpyAsync(dev + b * batch_bytes + first * 32, host + b * batch_bytes + first * 32, count * 32, hipMemcpyHostToDevice,
+                          copy_stream));
+    HIP_OK(hipEventRecord(ev, copy_stream));
   }
+  void copy(size_t b) const { copy_pairs(b, 0, batch_bytes / 32, ready[b & 1]); }
 };
+
+// Pairs of the first batch that are copied (and computed) ahead of the rest; 0 = no split.  The extra chunk costs one more
+// bucket reduction (~5 ms at 2^26), so it only pays when the copy it hides is longer than that.
+inline size_t first_piece_pairs(size_t n, size_t max_chunk) {
+  if (n < ((size_t)1 << 23)) return 0;
+  return std::min(n / 4, max_chunk);
+}
 
 template <class C>
 void run_device_t(mi355_msm_ctx* ctx, uint8_t* out, const uint32_t* d_scalars, size_t n, size_t batches, hipStream_t st,
@@ -404,20 +416,31 @@ void run_device_t(mi355_msm_ctx* ctx, uint8_t* out, const uint32_t* d_scalars, s
   typename E::Md md;
   const size_t max_chunk = ctx->opt_max_chunk ? (size_t)ctx->opt_max_chunk : ((size_t)1 << 26);
   const size_t out_bytes = 3 * 4 * E::WORDS;
-  if (hb && batches && n) hb->copy(0);
+  const size_t head = (hb && batches) ? first_piece_pairs(n, max_chunk) : 0;
+  if (hb && batches && n) {
+    if (head)
+      hb->copy_pairs(0, 0, head, hb->head);
+    else
+      hb->copy(0);
+  }
   for (size_t b = 0; b < batches; b++) {
     Xyzz total;
     xyzz_set_inf<E>(total);
-    if (hb && n) HIP_OK(hipStreamWaitEvent(st, hb->ready[b & 1], 0));
+    const bool split = head && b == 0;
+    if (hb && n) HIP_OK(hipStreamWaitEvent(st, split ? hb->head : hb->ready[b & 1], 0));
+    const std::function<void()> rest_of_first = [&] { hb->copy_pairs(0, head, n - head, hb->ready[0]); };
     const std::function<void()> prefetch = [&] {
       if (hb && b + 1 < batches) hb->copy(b + 1);
     };
-    for (size_t off = 0; off < n; off += max_chunk) {
-      size_t cn = std::min(max_chunk, n - off);
+    for (size_t off = 0; off < n;) {
+      const size_t cn = (split && off == 0) ? head : std::min(max_chunk, n - off);
       const bool last = off + cn >= n;
       Xyzz part;
-      run_chunk<C>(ctx, d_scalars + (b * n + off) * 8, off, cn, st, part, last ? &prefetch : nullptr);
+      if (split && off == head) HIP_OK(hipStreamWaitEvent(st, hb->ready[0], 0));
+      run_chunk<C>(ctx, d_scalars + (b * n + off) * 8, off, cn, st, part,
+                   (split && off == 0) ? &rest_of_first : (last ? &prefetch : nullptr));
       xyzz_add<E>(total, part, md);
+      off += cn;
     }
     xyzz_to_projective_abi<E>(out + b * out_bytes, total, md);
   }
@@ -467,8 +490,14 @@ RustError mi355_msm_create(mi355_msm_ctx** out, int curve, int device) {
     mi355_msm_ctx* ctx = new mi355_msm_ctx();
     ctx->curve = curve;
     ctx->device = device;
-    HIP_OK(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
-    for (auto& ev : ctx->ev) HIP_OK(hipEventCreate(&ev));
+    try {
+      HIP_OK(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
+      for (auto& ev : ctx->ev) HIP_OK(hipEventCreate(&ev));
+    } catch (...) {
+      RustError d = mi355_msm_destroy(ctx);
+      if (d.message) free(d.message);
+      throw;
+    }
     *out = ctx;
   });
 }
@@ -589,7 +618,8 @@ RustError mi355_msm_run(mi355_msm_ctx* ctx, void* out, const void* scalars, size
       HIP_OK(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
       for (auto& ev : ctx->copy_ev) HIP_OK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     }
-    HostBatches hb{(const uint8_t*)scalars, ctx->scalars.as<uint8_t>(), npoints * 32, ctx->copy_stream, {ctx->copy_ev[0], ctx->copy_ev[1]}};
+    HostBatches hb{(const uint8_t*)scalars, ctx->scalars.as<uint8_t>(), npoints * 32, ctx->copy_stream, {ctx->copy_ev[0], ctx->copy_ev[1]},
+                   ctx->copy_ev[2]};
     run_device(ctx, out, ctx->scalars.p, npoints, batches, ctx->own_stream, &hb);
   });
 }
