@@ -16,6 +16,7 @@ static void msm_check_fail(const char* file, int line, const char* cond) {
 #define MSM_CHECK_COL_END(col) MSM_CHECK(chk_col_ == (unsigned __int128)(col))
 
 #include "host_curve.hpp"
+#include "te.cuh"
 
 using namespace msm;
 
@@ -200,6 +201,32 @@ static void t_normalize(const uint8_t* in, uint8_t* out) {
   xyzz_to_projective_abi<E>(out, a, md);
 }
 
+// ---- twisted-Edwards image of BLS12-377 G1 (te.cuh) ------------------------------------------------------------
+using TF = Bls12_377_Fq;
+
+// arkworks Affine image -> TE base record; false when the point has no image (or is flagged infinite).
+static bool te_map_host(TeAffine& out, const uint8_t* img, const Modulus<TF>& md) {
+  using E = FpEl<TF>;
+  Affine p;
+  if (affine_from_abi<E>(p, img, md)) return false;
+  fe_reduce<TF>(p.x);
+  fe_reduce<TF>(p.y);
+  Fe u, v, w, den, inv;
+  te_map_prepare<TF>(u, v, w, den, p, md);
+  if (fe_is_zero_slow<TF>(den)) return false;
+  fe_inv<TF>(inv, den, md);
+  te_map_finish<TF>(out, u, v, w, inv, md);
+  return true;
+}
+
+static int te_finish_host(uint8_t* out, const Xyzz& acc, const Modulus<TF>& md) {
+  if (te_failed<TF>(acc)) return 2;
+  Xyzz sw;
+  te_to_sw<TF>(sw, acc, md);
+  xyzz_to_projective_abi<FpEl<TF>>(out, sw, md);
+  return 0;
+}
+
 #define DISPATCH_F(curve, fn, ...)                        \
   switch (curve) {                                        \
     case 0: fn<Bls12_377_Fq>(__VA_ARGS__); return 0;      \
@@ -230,4 +257,57 @@ int ht_madd_chain(int curve, const uint8_t* pts, size_t stride, const uint8_t* n
 int ht_add_chains(int curve, const uint8_t* pts, size_t stride, size_t na, size_t nb, uint8_t* out) { DISPATCH_C(curve, t_add_chains, pts, stride, na, nb, out) }
 int ht_msm_naive(int curve, const uint8_t* pts, size_t stride, const uint8_t* scalars, size_t n, uint8_t* out) { DISPATCH_C(curve, t_msm_naive, pts, stride, scalars, n, out) }
 int ht_normalize(int curve, const uint8_t* in, uint8_t* out) { DISPATCH_C(curve, t_normalize, in, out) }
+
+// (X, Y, 2dXY) of the image of an arkworks Affine image, as three ABI Montgomery field images; 1 = no image.
+int ht_te_map(const uint8_t* img, uint8_t* out) {
+  Modulus<TF> md;
+  TeAffine t;
+  if (!te_map_host(t, img, md)) return 1;
+  uint32_t w[36];
+  fe_to_abi<TF>(w, t.x, md);
+  fe_to_abi<TF>(w + 12, t.y, md);
+  fe_to_abi<TF>(w + 24, t.td, md);
+  memcpy(out, w, 144);
+  return 0;
+}
+// sum of (+/-) points through te_from_affine (first) and te_madd (rest), mapped back: a Projective image.
+// 1 = a point without image, 2 = an addition hit a vanishing denominator (Z = 0).
+int ht_te_madd_chain(const uint8_t* pts, size_t stride, const uint8_t* neg, size_t n, uint8_t* out) {
+  Modulus<TF> md;
+  Xyzz acc;
+  te_set_identity<TF>(acc);
+  bool fresh = true;
+  for (size_t i = 0; i < n; i++) {
+    if (pts[i * stride + 96]) continue;
+    TeAffine t;
+    if (!te_map_host(t, pts + i * stride, md)) return 1;
+    if (fresh)
+      te_from_affine<TF>(acc, t, neg[i] != 0, md);
+    else
+      te_madd<TF>(acc, t, neg[i] != 0, md);
+    fresh = false;
+    if (te_failed<TF>(acc)) return 2;
+  }
+  return te_finish_host(out, acc, md);
+}
+// (chain over the first na points) + (chain over the rest) through the unified extended addition, then `dbl` doublings.
+int ht_te_add_chains(const uint8_t* pts, size_t stride, size_t na, size_t nb, int dbl, uint8_t* out) {
+  Modulus<TF> md;
+  Xyzz a, b;
+  te_set_identity<TF>(a);
+  te_set_identity<TF>(b);
+  for (size_t i = 0; i < na + nb; i++) {
+    if (pts[i * stride + 96]) continue;
+    TeAffine t;
+    if (!te_map_host(t, pts + i * stride, md)) return 1;
+    te_madd<TF>(i < na ? a : b, t, false, md);
+  }
+  te_add<TF>(a, b, md);
+  if (te_failed<TF>(a)) return 2;
+  for (int i = 0; i < dbl; i++) {
+    te_dbl<TF>(a, md);
+    if (te_failed<TF>(a)) return 2;
+  }
+  return te_finish_host(out, a, md);
+}
 }

@@ -1,0 +1,45 @@
+// kernels_377te.hip -- the walking kernels instantiated for the twisted-Edwards image of BLS12-377 G1 (te.cuh, laws.cuh),
+// and the base converter.  Its own translation unit so that it compiles in parallel with the per-curve units.
+#include "launch.hpp"
+#include "msm_kernels.cuh"
+
+namespace msm {
+
+namespace {
+using G = TeLaw<Bls12_377_Fq>;
+inline uint32_t te_blocks(uint64_t n) { return (uint32_t)((n + 255) / 256); }
+}  // namespace
+
+hipError_t LaunchTe::convert(const AffineDev* in, const uint8_t* inf, uint32_t n, uint32_t J, Fe* prefix, TeAffineDev* out, uint32_t* flags,
+                             hipStream_t st) {
+  hipLaunchKernelGGL((k_te_convert<Bls12_377_Fq>), dim3(te_blocks(((uint64_t)n + J - 1) / J)), dim3(256), 0, st, in, inf, n, J, prefix, out, flags);
+  return hipGetLastError();
+}
+
+hipError_t LaunchTe::accumulate(const uint32_t* keys, const uint32_t* vals, uint32_t n_entries, uint32_t K, uint32_t sentinel,
+                                const TeAffineDev* bases, SegOut out, uint32_t nlanes, uint32_t* flags, hipStream_t st) {
+  #ifdef TE_ONE_LANE_GATHER
+  hipLaunchKernelGGL((k_accumulate<G>), dim3(te_blocks(nlanes)), dim3(256), 0, st, keys, vals, n_entries, K, sentinel, bases, out, nlanes, flags);
+#else
+  hipLaunchKernelGGL((k_accumulate_coop<G>), dim3(te_blocks(nlanes)), dim3(256), 0, st, keys, vals, n_entries, K, sentinel, bases, out, nlanes, flags);
+#endif
+  return hipGetLastError();
+}
+
+hipError_t LaunchTe::segreduce(const XyzzDev* in_slots, const uint32_t* in_keys, uint32_t n_in, uint32_t K, SegOut out, uint32_t nlanes,
+                               uint32_t* flags, hipStream_t st) {
+  hipLaunchKernelGGL((k_segreduce<G>), dim3(te_blocks(nlanes)), dim3(256), 0, st, in_slots, in_keys, n_in, K, out, nlanes, flags);
+  return hipGetLastError();
+}
+
+hipError_t LaunchTe::bucket_reduce(bool first, const XyzzDev* in_a, const XyzzDev* in_x, uint32_t n_per_win, uint32_t logL, uint32_t chunks,
+                                   uint32_t windows, XyzzDev* out_a, XyzzDev* out_x, uint32_t* flags, hipStream_t st) {
+  dim3 grid(te_blocks((uint64_t)windows * chunks));
+  if (first)
+    hipLaunchKernelGGL((k_bucket_reduce<G, true>), grid, dim3(256), 0, st, in_a, in_x, n_per_win, logL, chunks, windows, out_a, out_x, flags);
+  else
+    hipLaunchKernelGGL((k_bucket_reduce<G, false>), grid, dim3(256), 0, st, in_a, in_x, n_per_win, logL, chunks, windows, out_a, out_x, flags);
+  return hipGetLastError();
+}
+
+}  // namespace msm

@@ -6,6 +6,7 @@
 
 #include "host_curve.hpp"
 #include "msm_types.cuh"
+#include "te.cuh"
 
 namespace msm {
 
@@ -23,6 +24,19 @@ struct Launch {
                                   hipStream_t st);
   static hipError_t bucket_reduce(bool first, const XyzzDevT<El>* in_a, const XyzzDevT<El>* in_x, uint32_t n_per_win, uint32_t logL,
                                   uint32_t chunks, uint32_t windows, XyzzDevT<El>* out_a, XyzzDevT<El>* out_x, hipStream_t st);
+};
+
+// The twisted-Edwards fast path of BLS12-377 G1 (kernels_377te.hip).  `flags`: [0] += bases without an image (convert),
+// [1] = 1 when an addition hit a vanishing denominator (any walking kernel).
+struct LaunchTe {
+  static hipError_t convert(const AffineDev* in, const uint8_t* inf, uint32_t n, uint32_t J, Fe* prefix, TeAffineDev* out, uint32_t* flags,
+                            hipStream_t st);
+  static hipError_t accumulate(const uint32_t* keys, const uint32_t* vals, uint32_t n_entries, uint32_t K, uint32_t sentinel,
+                               const TeAffineDev* bases, SegOut out, uint32_t nlanes, uint32_t* flags, hipStream_t st);
+  static hipError_t segreduce(const XyzzDev* in_slots, const uint32_t* in_keys, uint32_t n_in, uint32_t K, SegOut out, uint32_t nlanes,
+                              uint32_t* flags, hipStream_t st);
+  static hipError_t bucket_reduce(bool first, const XyzzDev* in_a, const XyzzDev* in_x, uint32_t n_per_win, uint32_t logL, uint32_t chunks,
+                                  uint32_t windows, XyzzDev* out_a, XyzzDev* out_x, uint32_t* flags, hipStream_t st);
 };
 
 extern template struct Launch<Bls12_377_G1::E>;

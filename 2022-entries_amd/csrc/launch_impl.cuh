@@ -20,14 +20,15 @@ hipError_t Launch<E>::convert_bases(const uint8_t* in, size_t stride, uint32_t n
 template <class E>
 hipError_t Launch<E>::accumulate(const uint32_t* keys, const uint32_t* vals, uint32_t n_entries, uint32_t K, uint32_t sentinel,
                                  const AffineDevT<El>* bases, SegOutT<El> out, uint32_t nlanes, hipStream_t st) {
-  hipLaunchKernelGGL((k_accumulate<E>), dim3(launch_blocks(nlanes)), dim3(256), 0, st, keys, vals, n_entries, K, sentinel, bases, out, nlanes);
+  hipLaunchKernelGGL((k_accumulate<SwLaw<E>>), dim3(launch_blocks(nlanes)), dim3(256), 0, st, keys, vals, n_entries, K, sentinel, bases, out, nlanes,
+                     (uint32_t*)nullptr);
   return hipGetLastError();
 }
 
 template <class E>
 hipError_t Launch<E>::segreduce(const XyzzDevT<El>* in_slots, const uint32_t* in_keys, uint32_t n_in, uint32_t K, SegOutT<El> out,
                                 uint32_t nlanes, hipStream_t st) {
-  hipLaunchKernelGGL((k_segreduce<E>), dim3(launch_blocks(nlanes)), dim3(256), 0, st, in_slots, in_keys, n_in, K, out, nlanes);
+  hipLaunchKernelGGL((k_segreduce<SwLaw<E>>), dim3(launch_blocks(nlanes)), dim3(256), 0, st, in_slots, in_keys, n_in, K, out, nlanes, (uint32_t*)nullptr);
   return hipGetLastError();
 }
 
@@ -36,9 +37,11 @@ hipError_t Launch<E>::bucket_reduce(bool first, const XyzzDevT<El>* in_a, const 
                                     uint32_t chunks, uint32_t windows, XyzzDevT<El>* out_a, XyzzDevT<El>* out_x, hipStream_t st) {
   dim3 grid(launch_blocks((uint64_t)windows * chunks));
   if (first)
-    hipLaunchKernelGGL((k_bucket_reduce<E, true>), grid, dim3(256), 0, st, in_a, in_x, n_per_win, logL, chunks, windows, out_a, out_x);
+    hipLaunchKernelGGL((k_bucket_reduce<SwLaw<E>, true>), grid, dim3(256), 0, st, in_a, in_x, n_per_win, logL, chunks, windows, out_a, out_x,
+                       (uint32_t*)nullptr);
   else
-    hipLaunchKernelGGL((k_bucket_reduce<E, false>), grid, dim3(256), 0, st, in_a, in_x, n_per_win, logL, chunks, windows, out_a, out_x);
+    hipLaunchKernelGGL((k_bucket_reduce<SwLaw<E>, false>), grid, dim3(256), 0, st, in_a, in_x, n_per_win, logL, chunks, windows, out_a, out_x,
+                       (uint32_t*)nullptr);
   return hipGetLastError();
 }
 

@@ -1,0 +1,81 @@
+// laws.cuh -- the group-law policies the walking kernels (k_accumulate, k_segreduce, k_bucket_reduce) are written against.
+//
+//   SwLaw<E>  short Weierstrass, XYZZ accumulators, affine (x, y) base records            -- every curve (curve.cuh)
+//   TeLaw<F>  twisted-Edwards image of BLS12-377 G1, extended accumulators, (X, Y, 2dXY)   -- the fast path (te.cuh)
+//
+// Interface:  Point (always XyzzT<T>: the 4-coordinate accumulator, so slots/buckets/fragments share one layout),
+//   Base/BaseDev (what a lane gathers), set_identity, madd(acc, base, negate, fresh), add(acc, b) where b may be an
+//   all-zero "empty" record (a bucket nobody wrote), mul_pow2(acc, k), and failed(acc): true when the law could not
+//   compute the last result (TeLaw only: a vanishing denominator off the odd-order subgroup) -- kernels raise a flag then.
+#pragma once
+#include "curve.cuh"
+#include "msm_types.cuh"
+#include "te.cuh"
+
+namespace msm {
+
+template <class E_>
+struct SwLaw {
+  using E = E_;
+  using T = typename E::T;
+  using Md = typename E::Md;
+  using Base = AffineT<T>;
+  using BaseDev = AffineDevT<T>;
+  static constexpr bool CHECKS = false;
+  static constexpr int ACC_WAVES = E::ACC_WAVES;
+  static constexpr bool PREFETCH_BASE = E::PREFETCH_BASE;
+  static constexpr bool COOP_GATHER = false;
+  static MSM_HD void set_identity(XyzzT<T>& r) { xyzz_set_inf<E>(r); }
+  static MSM_HD void madd(XyzzT<T>& acc, const Base& b, bool negate, bool fresh, const Md& md) { xyzz_madd<E>(acc, b, negate, fresh, md); }
+  static MSM_HD void add(XyzzT<T>& acc, const XyzzT<T>& b, const Md& md) { xyzz_add<E>(acc, b, md); }
+  static MSM_HD void mul_pow2(XyzzT<T>& acc, uint32_t k, const Md& md) {
+    if (xyzz_is_inf<E>(acc)) return;
+    for (uint32_t i = 0; i < k; i++) xyzz_dbl<E>(acc, md);
+  }
+  static MSM_HD bool failed(const XyzzT<T>&) { return false; }
+};
+
+template <class F>
+struct TeLaw {
+  using E = FpEl<F>;
+  using T = Fe;
+  using Md = Modulus<F>;
+  using Base = TeAffine;
+  using BaseDev = TeAffineDev;
+  static constexpr bool CHECKS = true;
+#ifndef TE_ACC_WAVES
+#define TE_ACC_WAVES 2
+#endif
+#ifndef TE_PREFETCH
+#define TE_PREFETCH true
+#endif
+  static constexpr int ACC_WAVES = TE_ACC_WAVES;
+  static constexpr bool PREFETCH_BASE = TE_PREFETCH;
+  // quad-cooperative gathers (k_accumulate_coop): a 192-B record slot padded to 208 B so that the lanes' 16-B reads spread over
+  // the LDS banks (a 192-B stride would put every fourth lane on the same banks)
+  static constexpr bool COOP_GATHER = true;
+  static constexpr int COOP_LDS_STRIDE = 208;
+  static MSM_HD void set_identity(Xyzz& r) { te_set_identity<F>(r); }
+  // A run's first element is added onto the identity through the same 7M formula: a cheaper "copy" branch would be taken by
+  // some lane of a wave at most positions (runs are ~64 entries long), so the whole wave would pay for both paths.
+  static MSM_HD void madd(Xyzz& acc, const Base& b, bool negate, bool fresh, const Md& md) {
+    Xyzz id;
+    te_set_identity<F>(id);
+    fe_cmov(acc.x, id.x, fresh);
+    fe_cmov(acc.y, id.y, fresh);
+    fe_cmov(acc.zz, id.zz, fresh);
+    fe_cmov(acc.zzz, id.zzz, fresh);
+    te_madd<F>(acc, b, negate, md);
+  }
+  // Z = 0 never occurs in a valid point: it marks an empty (zero-filled) bucket, which adds nothing.
+  static MSM_HD void add(Xyzz& acc, const Xyzz& b, const Md& md) {
+    if (fe_is_zero_M<F>(b.zz)) return;
+    te_add<F>(acc, b, md);
+  }
+  static MSM_HD void mul_pow2(Xyzz& acc, uint32_t k, const Md& md) {
+    for (uint32_t i = 0; i < k; i++) te_dbl<F>(acc, md);
+  }
+  static MSM_HD bool failed(const Xyzz& a) { return te_failed<F>(a); }
+};
+
+}  // namespace msm

@@ -17,6 +17,7 @@
 #include <rocprim/rocprim.hpp>
 #include <functional>
 #include <stdexcept>
+#include <type_traits>
 #include <string>
 #include <vector>
 
@@ -141,6 +142,13 @@ struct mi355_msm_ctx {
   hipEvent_t ev[8] = {};
   long opt_window_bits = 0, opt_lane_entries = 0, opt_max_chunk = 0, opt_seg_entries = 0, opt_scalars_montgomery = 0;
   long opt_precompute = 0;
+  long opt_twisted_edwards = 1;   // BLS12-377 G1 only: accumulate on the twisted-Edwards image when every base has one
+  // twisted-Edwards fast path (te.cuh): records for every table level; te_active is decided per base set
+  DevBuf te_bases, flags;         // flags: u32[2] on the device, [0] bases without an image, [1] an addition failed
+  uint32_t* h_flags = nullptr;    // pinned copy
+  bool te_active = false;
+  bool sw_level0_only = false;    // the short-Weierstrass tables were dropped after conversion (only level 0 is kept)
+  uint64_t te_fallbacks = 0;      // runs repeated on the XYZZ path because an addition reported a vanishing denominator
   // precomputed tables (row f1): level w at bases[w * nbases ...] holds 2^(pre_c * w) * P; 0 = none
   uint32_t pre_c = 0, pre_windows = 0;
   bool bases_serialized = false;  // set only for the duration of mi355_msm_set_bases_serialized
@@ -149,14 +157,17 @@ struct mi355_msm_ctx {
 
   int scalar_bits() const { return curve == MI355_BLS12_381_G1 ? 255 : 253; }
 
-  Plan plan(size_t n) const {
+  // use_tables = false plans the run WITHOUT the precomputed tables of this context (the XYZZ fallback of a
+  // twisted-Edwards context, whose short-Weierstrass tables were dropped)
+  Plan plan(size_t n, bool use_tables = true) const {
     Plan p{};
-    if (pre_c)
+    const bool tables = pre_c && use_tables;
+    if (tables)
       p.c = pre_c;
     else
-      p.c = opt_window_bits ? (uint32_t)opt_window_bits : (uint32_t)choose_window_bits(n, scalar_bits(), false);
+      p.c = (opt_window_bits && !pre_c) ? (uint32_t)opt_window_bits : (uint32_t)choose_window_bits(n, scalar_bits(), false);
     p.windows = (257 + p.c - 1) / p.c;
-    p.bucket_windows = pre_c ? 1 : p.windows;
+    p.bucket_windows = tables ? 1 : p.windows;
     p.half = 1u << (p.c - 1);
     p.sentinel = p.bucket_windows * p.half;
     p.keybits = ilog2_floor(p.sentinel) + 1;
@@ -244,6 +255,49 @@ void build_tables(mi355_msm_ctx* ctx, const uint8_t* d_raw, size_t n, size_t str
   ctx->pre_windows = windows;
 }
 
+// BLS12-377 G1: twisted-Edwards records for every table level (te.cuh).  The base set takes the fast path only if every
+// (non-infinite) entry has an image; otherwise, or when the records do not fit, the context stays on XYZZ.
+void build_te(mi355_msm_ctx* ctx, size_t n, hipStream_t st) {
+  const size_t levels = ctx->pre_c ? ctx->pre_windows : 1;
+  const size_t total = levels * n;
+  size_t free_b = 0, total_b = 0;
+  HIP_OK(hipMemGetInfo(&free_b, &total_b));
+  const size_t need = total * sizeof(TeAffineDev) + n * sizeof(Fe) + ((size_t)1 << 30);
+  if (need > free_b + ctx->te_bases.bytes) return;   // not an error: the XYZZ path needs nothing more
+  ctx->te_bases.reserve(total * sizeof(TeAffineDev));
+  ctx->flags.reserve(2 * sizeof(uint32_t));
+  if (!ctx->h_flags) HIP_OK(hipHostMalloc((void**)&ctx->h_flags, 2 * sizeof(uint32_t), hipHostMallocDefault));
+  HIP_OK(hipMemsetAsync(ctx->flags.p, 0, 2 * sizeof(uint32_t), st));
+  DevBuf prefix;
+  try {
+    prefix.reserve(n * sizeof(Fe));
+    for (size_t w = 0; w < levels; w++)
+      HIP_OK(LaunchTe::convert(ctx->bases.as<AffineDev>() + w * n, ctx->inf.as<uint8_t>() + w * n, (uint32_t)n, 64, prefix.as<Fe>(),
+                               ctx->te_bases.as<TeAffineDev>() + w * n, ctx->flags.as<uint32_t>(), st));
+    HIP_OK(hipMemcpyAsync(ctx->h_flags, ctx->flags.p, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
+  } catch (...) {
+    prefix.release();
+    throw;
+  }
+  prefix.release();
+  if (ctx->h_flags[0] != 0) {   // a 2-torsion point or one of the two u = -1 points among the bases
+    ctx->te_bases.release();
+    return;
+  }
+  ctx->te_active = true;
+  if (levels > 1) {
+    // keep level 0 of the short-Weierstrass tables only: it serves the (rare) XYZZ fallback, without tables
+    DevBuf level0;
+    level0.reserve(n * sizeof(AffineDev));
+    HIP_OK(hipMemcpyAsync(level0.p, ctx->bases.p, n * sizeof(AffineDev), hipMemcpyDeviceToDevice, st));
+    HIP_OK(hipStreamSynchronize(st));
+    ctx->bases.release();
+    ctx->bases = level0;
+    ctx->sw_level0_only = true;
+  }
+}
+
 void set_bases_device(mi355_msm_ctx* ctx, const void* d_affine, size_t n, size_t stride) {
   ensure_device(ctx);
   const size_t min_stride = 2 * coord_bytes(ctx->curve) + (ctx->bases_serialized ? 0 : 1);
@@ -251,27 +305,53 @@ void set_bases_device(mi355_msm_ctx* ctx, const void* d_affine, size_t n, size_t
   if (n >= (1ull << 31)) bad_arg("npoints %zu exceeds 2^31-1", n);
   ctx->pre_c = ctx->pre_windows = 0;
   ctx->nbases = 0;
+  ctx->te_active = false;
+  ctx->sw_level0_only = false;
   if (n) {
     if (ctx->opt_precompute)
       with_curve(ctx->curve, [&]<class C>() { build_tables<C>(ctx, (const uint8_t*)d_affine, n, stride, ctx->own_stream); });
     else
       with_curve(ctx->curve, [&]<class C>() { convert_bases<C>(ctx, (const uint8_t*)d_affine, n, stride, ctx->own_stream); });
     HIP_OK(hipStreamSynchronize(ctx->own_stream));
+    if (ctx->curve == MI355_BLS12_377_G1 && ctx->opt_twisted_edwards) build_te(ctx, n, ctx->own_stream);
   }
   ctx->nbases = n;
 }
 
+// result = sum_w 2^(c*w) * sums[w] on the twisted-Edwards image, mapped back to short-Weierstrass XYZZ.
+// false: an addition hit a vanishing denominator (possible only off the odd-order subgroup).
+inline bool fold_windows_te(Xyzz& out, const Xyzz* sums, int windows, int c, const Modulus<Bls12_377_Fq>& md) {
+  using F = Bls12_377_Fq;
+  Xyzz acc;
+  te_set_identity<F>(acc);
+  for (int w = windows - 1; w >= 0; w--) {
+    if (w != windows - 1)
+      for (int i = 0; i < c; i++) {
+        te_dbl<F>(acc, md);
+        if (te_failed<F>(acc)) return false;
+      }
+    if (te_failed<F>(sums[w])) return false;
+    te_add<F>(acc, sums[w], md);
+    if (te_failed<F>(acc)) return false;
+  }
+  te_to_sw<F>(out, acc, md);
+  return true;
+}
+
 // One chunk of one batch: device scalars [0, n) against bases [base0, base0 + n).  Leaves the folded chunk sum in `out`.
-template <class C>
-void run_chunk(mi355_msm_ctx* ctx, const uint32_t* d_scalars, size_t base0, size_t n, hipStream_t st,
-               XyzzT<typename C::E::T>& out, const std::function<void()>* while_gpu_busy = nullptr) {
+// TE = true runs the twisted-Edwards kernels (BLS12-377 G1 contexts whose bases all have an image) and returns false when
+// an addition reported a vanishing denominator: the caller then repeats the chunk with TE = false.
+template <class C, bool TE>
+bool run_chunk_impl(mi355_msm_ctx* ctx, const uint32_t* d_scalars, size_t base0, size_t n, hipStream_t st,
+                    XyzzT<typename C::E::T>& out, const std::function<void()>* while_gpu_busy) {
   using E = typename C::E;
   using El = typename E::T;
   using XyzzDev = XyzzDevT<El>;
   using AffineDev = AffineDevT<El>;
   using SegOut = SegOutT<El>;
   using Xyzz = XyzzT<El>;
-  const Plan p = ctx->plan(n);
+  const bool use_tables = ctx->pre_c && (TE || !ctx->sw_level0_only);
+  const Plan p = ctx->plan(n, use_tables);
   if (p.entries >= (1ull << 32)) bad_arg("chunk of %zu pairs needs %llu sort entries (>= 2^32)", n, (unsigned long long)p.entries);
   const size_t NE = p.entries;
   for (int i = 0; i < 2; i++) {
@@ -304,7 +384,8 @@ void run_chunk(mi355_msm_ctx* ctx, const uint32_t* d_scalars, size_t base0, size
 
   const AffineDev* bases = ctx->bases.as<AffineDev>();
   const uint8_t* inf = ctx->inf.as<uint8_t>();
-  const uint32_t table_stride = ctx->pre_c ? (uint32_t)ctx->nbases : 0u;
+  const uint32_t table_stride = use_tables ? (uint32_t)ctx->nbases : 0u;
+  uint32_t* flags = ctx->flags.as<uint32_t>();
 
   HIP_OK(hipEventRecord(ctx->ev[0], st));
   using FR = typename C::FR;
@@ -321,7 +402,11 @@ void run_chunk(mi355_msm_ctx* ctx, const uint32_t* d_scalars, size_t base0, size
   HIP_OK(hipEventRecord(ctx->ev[2], st));
 
   SegOut so{ctx->buckets.as<XyzzDev>(), ctx->slots[0].as<XyzzDev>(), ctx->slot_keys[0].as<uint32_t>()};
-  HIP_OK(Launch<E>::accumulate(kbuf.current(), vbuf.current(), (uint32_t)p.entries, p.K, p.sentinel, bases, so, p.nlanes, st));
+  if constexpr (TE)
+    HIP_OK(LaunchTe::accumulate(kbuf.current(), vbuf.current(), (uint32_t)p.entries, p.K, p.sentinel, ctx->te_bases.as<TeAffineDev>(), so,
+                                p.nlanes, flags, st));
+  else
+    HIP_OK(Launch<E>::accumulate(kbuf.current(), vbuf.current(), (uint32_t)p.entries, p.K, p.sentinel, bases, so, p.nlanes, st));
   HIP_OK(hipEventRecord(ctx->ev[3], st));
 
   // merge the run fragments that crossed lane boundaries
@@ -332,7 +417,10 @@ void run_chunk(mi355_msm_ctx* ctx, const uint32_t* d_scalars, size_t base0, size
       uint32_t nl = ceil_div(n_in, p.segK);
       if (nl > 1 && 2 * (uint64_t)nl >= n_in) bad_arg("fragment merge would not shrink (%u slots, fan-in %u)", n_in, p.segK);
       SegOut o{ctx->buckets.as<XyzzDev>(), ctx->slots[cur ^ 1].as<XyzzDev>(), ctx->slot_keys[cur ^ 1].as<uint32_t>()};
-      HIP_OK(Launch<E>::segreduce(ctx->slots[cur].as<XyzzDev>(), ctx->slot_keys[cur].as<uint32_t>(), n_in, p.segK, o, nl, st));
+      if constexpr (TE)
+        HIP_OK(LaunchTe::segreduce(ctx->slots[cur].as<XyzzDev>(), ctx->slot_keys[cur].as<uint32_t>(), n_in, p.segK, o, nl, flags, st));
+      else
+        HIP_OK(Launch<E>::segreduce(ctx->slots[cur].as<XyzzDev>(), ctx->slot_keys[cur].as<uint32_t>(), n_in, p.segK, o, nl, st));
       if (nl == 1) break;
       n_in = 2 * nl;
       cur ^= 1;
@@ -343,18 +431,30 @@ void run_chunk(mi355_msm_ctx* ctx, const uint32_t* d_scalars, size_t base0, size
   // buckets -> one point per window
   uint32_t n_per_win = p.half, logL = p.logL0, chunks = p.T0;
   int rb = 0;
-  HIP_OK(Launch<E>::bucket_reduce(true, nullptr, ctx->buckets.as<XyzzDev>(), n_per_win, logL, chunks, p.bucket_windows,
-                                  ctx->red_a[0].as<XyzzDev>(), ctx->red_x[0].as<XyzzDev>(), st));
+  if constexpr (TE)
+    HIP_OK(LaunchTe::bucket_reduce(true, nullptr, ctx->buckets.as<XyzzDev>(), n_per_win, logL, chunks, p.bucket_windows,
+                                   ctx->red_a[0].as<XyzzDev>(), ctx->red_x[0].as<XyzzDev>(), flags, st));
+  else
+    HIP_OK(Launch<E>::bucket_reduce(true, nullptr, ctx->buckets.as<XyzzDev>(), n_per_win, logL, chunks, p.bucket_windows,
+                                    ctx->red_a[0].as<XyzzDev>(), ctx->red_x[0].as<XyzzDev>(), st));
   while (chunks > 1) {
     n_per_win = chunks;
     logL = p.logL;
     chunks = ceil_div(n_per_win, 1u << logL);
-    HIP_OK(Launch<E>::bucket_reduce(false, ctx->red_a[rb].as<XyzzDev>(), ctx->red_x[rb].as<XyzzDev>(), n_per_win, logL, chunks,
-                                    p.bucket_windows, ctx->red_a[rb ^ 1].as<XyzzDev>(), ctx->red_x[rb ^ 1].as<XyzzDev>(), st));
+    if constexpr (TE)
+      HIP_OK(LaunchTe::bucket_reduce(false, ctx->red_a[rb].as<XyzzDev>(), ctx->red_x[rb].as<XyzzDev>(), n_per_win, logL, chunks,
+                                     p.bucket_windows, ctx->red_a[rb ^ 1].as<XyzzDev>(), ctx->red_x[rb ^ 1].as<XyzzDev>(), flags, st));
+    else
+      HIP_OK(Launch<E>::bucket_reduce(false, ctx->red_a[rb].as<XyzzDev>(), ctx->red_x[rb].as<XyzzDev>(), n_per_win, logL, chunks,
+                                      p.bucket_windows, ctx->red_a[rb ^ 1].as<XyzzDev>(), ctx->red_x[rb ^ 1].as<XyzzDev>(), st));
     rb ^= 1;
   }
   HIP_OK(hipEventRecord(ctx->ev[5], st));
   HIP_OK(hipMemcpyAsync(ctx->pinned, ctx->red_a[rb].p, p.bucket_windows * sizeof(XyzzDev), hipMemcpyDeviceToHost, st));
+  if constexpr (TE) {
+    HIP_OK(hipMemcpyAsync(ctx->h_flags, flags, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    HIP_OK(hipMemsetAsync(flags + 1, 0, sizeof(uint32_t), st));
+  }
   HIP_OK(hipEventRecord(ctx->ev[6], st));
   // everything for this chunk is enqueued: host work that should hide behind it (the next batch's H2D copy) goes here
   if (while_gpu_busy) (*while_gpu_busy)();
@@ -364,7 +464,11 @@ void run_chunk(mi355_msm_ctx* ctx, const uint32_t* d_scalars, size_t base0, size
   std::vector<Xyzz> sums(p.bucket_windows);
   const XyzzDev* hs = reinterpret_cast<const XyzzDev*>(ctx->pinned);
   for (uint32_t w = 0; w < p.bucket_windows; w++) sums[w] = hs[w].p;
-  fold_windows<E>(out, sums.data(), (int)p.bucket_windows, (int)p.c, md);
+  bool ok = true;
+  if constexpr (TE)
+    ok = ctx->h_flags[1] == 0 && fold_windows_te(out, sums.data(), (int)p.bucket_windows, (int)p.c, md);
+  else
+    fold_windows<E>(out, sums.data(), (int)p.bucket_windows, (int)p.c, md);
 
   float ms = 0;
   for (int s = 0; s < 5; s++) {
@@ -380,6 +484,23 @@ void run_chunk(mi355_msm_ctx* ctx, const uint32_t* d_scalars, size_t base0, size
   ctx->last_info[3] = p.K;
   ctx->last_info[4] += 1;
   ctx->last_info[5] = p.nlanes;
+  ctx->last_info[7] = TE ? 1 : 0;
+  return ok;
+}
+
+template <class C>
+void run_chunk(mi355_msm_ctx* ctx, const uint32_t* d_scalars, size_t base0, size_t n, hipStream_t st,
+               XyzzT<typename C::E::T>& out, const std::function<void()>* while_gpu_busy = nullptr) {
+  if constexpr (std::is_same_v<C, Bls12_377_G1>) {
+    if (ctx->te_active) {
+      if (run_chunk_impl<C, true>(ctx, d_scalars, base0, n, st, out, while_gpu_busy)) return;
+      ctx->te_fallbacks++;
+      // (the hook -- the next batch's H2D copy -- has run already)
+      run_chunk_impl<C, false>(ctx, d_scalars, base0, n, st, out, nullptr);
+      return;
+    }
+  }
+  run_chunk_impl<C, false>(ctx, d_scalars, base0, n, st, out, while_gpu_busy);
 }
 
 // Streams the scalar batches of a host-pointer run: batch b+1 is copied while batch b computes
@@ -509,9 +630,10 @@ RustError mi355_msm_destroy(mi355_msm_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->own_stream);
     DevBuf* bufs[] = {&ctx->bases, &ctx->inf, &ctx->scalars, &ctx->keys[0], &ctx->keys[1], &ctx->vals[0], &ctx->vals[1],
                       &ctx->sort_tmp, &ctx->buckets, &ctx->slots[0], &ctx->slots[1], &ctx->slot_keys[0], &ctx->slot_keys[1],
-                      &ctx->red_a[0], &ctx->red_a[1], &ctx->red_x[0], &ctx->red_x[1]};
+                      &ctx->red_a[0], &ctx->red_a[1], &ctx->red_x[0], &ctx->red_x[1], &ctx->te_bases, &ctx->flags};
     for (DevBuf* b : bufs) b->release();
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->h_flags) (void)hipHostFree(ctx->h_flags);
     for (auto& ev : ctx->ev)
       if (ev) (void)hipEventDestroy(ev);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -652,6 +774,8 @@ RustError mi355_msm_set_option(mi355_msm_ctx* ctx, const char* key, long value) 
       // fan-in K maps n slots to 2*ceil(n/K); that only shrinks for K >= 4
       if (value != 0 && (value < 4 || value > 4096)) bad_arg("seg_entries %ld out of range [4, 4096]", value);
       ctx->opt_seg_entries = value;
+    } else if (k == "twisted_edwards") {
+      ctx->opt_twisted_edwards = value != 0;   // takes effect at the next set_bases
     } else if (k == "precompute") {
       ctx->opt_precompute = value != 0;   // takes effect at the next set_bases
     } else if (k == "scalars_montgomery") {
@@ -667,6 +791,27 @@ RustError mi355_msm_last_timings(mi355_msm_ctx* ctx, float* ms, uint64_t* info) 
     if (!ctx) bad_arg("null context");
     if (ms) memcpy(ms, ctx->last_ms, sizeof ctx->last_ms);
     if (info) memcpy(info, ctx->last_info, 6 * sizeof(uint64_t));
+  });
+}
+
+RustError mi355_msm_query(mi355_msm_ctx* ctx, const char* key, uint64_t* value) {
+  return guarded([&] {
+    if (!ctx || !key || !value) bad_arg("null argument");
+    std::string k(key);
+    if (k == "twisted_edwards")
+      *value = ctx->te_active ? 1 : 0;
+    else if (k == "twisted_edwards_fallbacks")
+      *value = ctx->te_fallbacks;
+    else if (k == "bases")
+      *value = ctx->nbases;
+    else if (k == "table_levels")
+      *value = ctx->pre_c ? ctx->pre_windows : (ctx->nbases ? 1 : 0);
+    else if (k == "table_window_bits")
+      *value = ctx->pre_c;
+    else if (k == "base_bytes")
+      *value = ctx->bases.bytes + ctx->te_bases.bytes + ctx->inf.bytes;
+    else
+      bad_arg("unknown query '%s'", key);
   });
 }
 

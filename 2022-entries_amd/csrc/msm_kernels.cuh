@@ -8,6 +8,9 @@
 //                     go to per-lane head/tail slots
 //   k_segreduce       merges the slot fragments (same walk, full XYZZ add), recursively
 //   k_bucket_reduce   sum_b b * bucket[b] per window by chunked running sums, recursively
+//   k_te_convert      short-Weierstrass base records -> twisted-Edwards records (BLS12-377 G1 fast path, te.cuh)
+// The three walking kernels are generic over a group-law policy (laws.cuh): XYZZ for every curve, extended twisted Edwards
+// for BLS12-377 G1.
 //
 // Reference behaviour covered: digit extraction SPK msm/pippenger.cuh:116-123, signed digits
 // CMB ProcessSignedDigits.cu:118-151 / P1A mikevoronov sppark/msm/pippenger.cuh:453-479; bucket
@@ -18,6 +21,7 @@
 // (one hot bucket, the sparse top window) cost the same as uniform ones.
 #pragma once
 #include "curve.cuh"
+#include "laws.cuh"
 #include "msm_types.cuh"
 
 namespace msm {
@@ -88,11 +92,13 @@ __device__ __forceinline__ void seg_flush(const SegOutT<T>& o, uint32_t t, uint3
 
 // The hot kernel.  Lane t walks sorted entries [t*K, (t+1)*K): ~K mixed adds, one bucket store per run.
 // The next base is fetched before the current add so the gather latency hides under ~5k VALU ops.
-template <class E>
-__global__ void __launch_bounds__(256, E::ACC_WAVES) k_accumulate(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
+// G = the group-law policy (laws.cuh); `flags[1]` is raised when the law reports a result it could not compute.
+template <class G>
+__global__ void __launch_bounds__(256, G::ACC_WAVES) k_accumulate(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
                                                     uint32_t n_entries, uint32_t K, uint32_t sentinel,
-                                                    const AffineDevT<typename E::T>* __restrict__ bases,
-                                                    SegOutT<typename E::T> out, uint32_t nlanes) {
+                                                    const typename G::BaseDev* __restrict__ bases,
+                                                    SegOutT<typename G::T> out, uint32_t nlanes, uint32_t* __restrict__ flags) {
+  using E = typename G::E;
   const uint32_t t = blockIdx.x * 256 + threadIdx.x;
   if (t >= nlanes) return;
   typename E::Md md;
@@ -112,22 +118,22 @@ __global__ void __launch_bounds__(256, E::ACC_WAVES) k_accumulate(const uint32_t
     key_n = keys[beg + 1];
     val_n = vals[beg + 1];
   }
-  // (E::PREFETCH_BASE = false -- G2, whose accumulator alone is 112 VGPRs -- gathers the base at its point of use instead)
-  AffineT<typename E::T> p_c;
-  if (E::PREFETCH_BASE && key_c != sentinel) p_c = bases[val_c & IDX_MASK].p;
+  // (G::PREFETCH_BASE = false -- G2, whose accumulator alone is 112 VGPRs -- gathers the base at its point of use instead)
+  typename G::Base p_c;
+  if (G::PREFETCH_BASE && key_c != sentinel) p_c = bases[val_c & IDX_MASK].p;
 
   uint32_t cur = KEY_NONE;
-  bool first = true, fresh = true;
-  XyzzT<typename E::T> acc;
-  xyzz_set_inf<E>(acc);
+  bool first = true, fresh = true, bad = false;
+  XyzzT<typename G::T> acc;
+  G::set_identity(acc);
   for (uint32_t e = beg; e < end; e++) {
     const uint32_t key = key_c, val = val_c;
     if (key == sentinel) break;  // sorted: nothing but sentinels from here on
-    if (!E::PREFETCH_BASE) p_c = bases[val & IDX_MASK].p;
-    const AffineT<typename E::T> p = p_c;
+    if (!G::PREFETCH_BASE) p_c = bases[val & IDX_MASK].p;
+    const typename G::Base p = p_c;
     key_c = key_n;
     val_c = val_n;
-    if (E::PREFETCH_BASE && end - e > 1 && key_c != sentinel) p_c = bases[val_c & IDX_MASK].p;
+    if (G::PREFETCH_BASE && end - e > 1 && key_c != sentinel) p_c = bases[val_c & IDX_MASK].p;
     if (end - e > 2) {
       key_n = keys[e + 2];
       val_n = vals[e + 2];
@@ -142,18 +148,141 @@ __global__ void __launch_bounds__(256, E::ACC_WAVES) k_accumulate(const uint32_t
       cur = key;
       fresh = true;
     }
-    xyzz_madd<E>(acc, p, (val >> 31) != 0, fresh, md);
+    G::madd(acc, p, (val >> 31) != 0, fresh, md);
+    if (G::CHECKS) bad |= G::failed(acc);
     fresh = false;
   }
   if (cur != KEY_NONE) seg_flush(out, t, nlanes, cur, acc, first, true);
+  if (G::CHECKS && bad) flags[1] = 1;
+}
+
+// The same walk with QUAD-COOPERATIVE gathers (laws with COOP_GATHER).  tools/ubench_gather.hip: when every lane of a wave
+// loads 16 B from its own random record, the texture-address path resolves ~80 G lane-loads/s chip-wide -- 1.3 TB/s, 6.6 G
+// 192-B records/s, which is where a one-lane-per-record gather of twisted-Edwards bases stalls (VALU 72 % busy).  When the four
+// lanes of a quad fetch their four records TOGETHER, lane l taking bytes [16 l, 16 l + 16) of every 64-B sector, one
+// wave-instruction touches 16 lines instead of 64 and the same chip gathers 24 G records/s (4.7 TB/s).  The pieces cross lanes
+// through LDS: every lane writes the 4 x SECT pieces it fetched into the quad's four record slots and reads its own record
+// back as one contiguous run (same-wave LDS traffic is ordered, so no barrier; slots are padded against bank conflicts).
+// All lanes of a wave stay in the loop until the whole wave is done, because the quad needs all four of them.
+template <class G>
+__global__ void __launch_bounds__(256, G::ACC_WAVES) k_accumulate_coop(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
+                                                         uint32_t n_entries, uint32_t K, uint32_t sentinel,
+                                                         const typename G::BaseDev* __restrict__ bases,
+                                                         SegOutT<typename G::T> out, uint32_t nlanes, uint32_t* __restrict__ flags) {
+  using E = typename G::E;
+  using Base = typename G::Base;
+  constexpr int SECT = sizeof(typename G::BaseDev) / 64;   // 64-B sectors per record
+  constexpr int LS = G::COOP_LDS_STRIDE;                   // bytes per record slot in LDS
+  constexpr int PIECES = (sizeof(Base) + 15) / 16;
+  static_assert(sizeof(typename G::BaseDev) % 64 == 0 && LS % 16 == 0 && LS >= SECT * 64 && LS >= PIECES * 16, "record slot layout");
+  __shared__ __attribute__((aligned(16))) unsigned char lds[256 * LS];
+  const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+  const uint32_t sub = threadIdx.x & 3;
+  typename E::Md md;
+  const bool lane_ok = t < nlanes;
+  if (lane_ok) {
+    out.slot_keys[2 * (size_t)t] = KEY_NONE;
+    out.slot_keys[2 * (size_t)t + 1] = KEY_NONE;
+  }
+  const uint64_t beg64 = (uint64_t)t * K;
+  const bool has_work = lane_ok && beg64 < n_entries;
+  const uint32_t beg = has_work ? (uint32_t)beg64 : 0;
+  const uint32_t end = has_work ? ((n_entries - beg > K) ? beg + K : n_entries) : 0;
+
+  uint32_t key_c = sentinel, val_c = 0, key_n = sentinel, val_n = 0;
+  if (end > beg) {
+    key_c = keys[beg];
+    val_c = vals[beg];
+    if (end - beg > 1) {
+      key_n = keys[beg + 1];
+      val_n = vals[beg + 1];
+    }
+  }
+  bool alive = key_c != sentinel;
+
+  // The quad's four gathers: record i belongs to quad lane i; a lane without a next entry asks for record 0.
+  // (Twelve named registers and macros rather than an array and lambdas: hipcc leaves a loop-carried array in scratch.)
+  static_assert(SECT == 3, "the piece registers below are written out for three-sector records");
+  uint4 q00, q01, q02, q10, q11, q12, q20, q21, q22, q30, q31, q32;
+#define MSM_COOP_ISSUE(val, valid)                                                                                      \
+  do {                                                                                                                  \
+    const int mine_ = (valid) ? (int)((val) & IDX_MASK) : 0;                                                            \
+    const uint4* s0_ = reinterpret_cast<const uint4*>(bases + (uint32_t)__builtin_amdgcn_update_dpp(0, mine_, 0x00, 0xf, 0xf, true)) + sub; \
+    const uint4* s1_ = reinterpret_cast<const uint4*>(bases + (uint32_t)__builtin_amdgcn_update_dpp(0, mine_, 0x55, 0xf, 0xf, true)) + sub; \
+    const uint4* s2_ = reinterpret_cast<const uint4*>(bases + (uint32_t)__builtin_amdgcn_update_dpp(0, mine_, 0xaa, 0xf, 0xf, true)) + sub; \
+    const uint4* s3_ = reinterpret_cast<const uint4*>(bases + (uint32_t)__builtin_amdgcn_update_dpp(0, mine_, 0xff, 0xf, 0xf, true)) + sub; \
+    q00 = s0_[0]; q01 = s0_[4]; q02 = s0_[8];                                                                           \
+    q10 = s1_[0]; q11 = s1_[4]; q12 = s1_[8];                                                                           \
+    q20 = s2_[0]; q21 = s2_[4]; q22 = s2_[8];                                                                           \
+    q30 = s3_[0]; q31 = s3_[4]; q32 = s3_[8];                                                                           \
+  } while (0)
+#define MSM_COOP_PUT(i, c, reg) *reinterpret_cast<uint4*>(quad_slots + (i) * LS + (c) * 64 + sub * 16) = reg
+
+  MSM_COOP_ISSUE(val_c, alive);
+  uint32_t cur = KEY_NONE;
+  bool first = true, fresh = true, bad = false;
+  XyzzT<typename G::T> acc;
+  G::set_identity(acc);
+  for (uint32_t k = 0; k < K; k++) {
+    if (__builtin_amdgcn_ballot_w64(alive) == 0) break;   // wave-uniform: every lane of the wave has run out
+    // hand the pieces over through LDS and read this lane's record back as one contiguous run
+    Base p;
+    {
+      unsigned char* quad_slots = lds + (threadIdx.x & ~3u) * LS;
+      MSM_COOP_PUT(0, 0, q00); MSM_COOP_PUT(0, 1, q01); MSM_COOP_PUT(0, 2, q02);
+      MSM_COOP_PUT(1, 0, q10); MSM_COOP_PUT(1, 1, q11); MSM_COOP_PUT(1, 2, q12);
+      MSM_COOP_PUT(2, 0, q20); MSM_COOP_PUT(2, 1, q21); MSM_COOP_PUT(2, 2, q22);
+      MSM_COOP_PUT(3, 0, q30); MSM_COOP_PUT(3, 1, q31); MSM_COOP_PUT(3, 2, q32);
+      const uint4* mine = reinterpret_cast<const uint4*>(lds + threadIdx.x * LS);
+      uint32_t* dst = reinterpret_cast<uint32_t*>(&p);
+#pragma unroll
+      for (int q = 0; q < PIECES; q++) {
+        const uint4 v = mine[q];
+        if (4 * q < (int)(sizeof(Base) / 4)) dst[4 * q] = v.x;
+        if (4 * q + 1 < (int)(sizeof(Base) / 4)) dst[4 * q + 1] = v.y;
+        if (4 * q + 2 < (int)(sizeof(Base) / 4)) dst[4 * q + 2] = v.z;
+        if (4 * q + 3 < (int)(sizeof(Base) / 4)) dst[4 * q + 3] = v.w;
+      }
+    }
+    const uint32_t key = key_c, val = val_c, e = beg + k;
+    const bool add_now = alive;
+    key_c = key_n;
+    val_c = val_n;
+    alive = add_now && (end - e > 1) && key_c != sentinel;
+    MSM_COOP_ISSUE(val_c, alive);
+    if (add_now && end - e > 2) {
+      key_n = keys[e + 2];
+      val_n = vals[e + 2];
+    } else {
+      key_n = sentinel;
+    }
+    if (add_now) {
+      if (key != cur) {
+        if (cur != KEY_NONE) {
+          seg_flush(out, t, nlanes, cur, acc, first, false);
+          first = false;
+        }
+        cur = key;
+        fresh = true;
+      }
+      G::madd(acc, p, (val >> 31) != 0, fresh, md);
+      if (G::CHECKS) bad |= G::failed(acc);
+      fresh = false;
+    }
+  }
+  if (cur != KEY_NONE) seg_flush(out, t, nlanes, cur, acc, first, true);
+  if (G::CHECKS && bad) flags[1] = 1;
+#undef MSM_COOP_ISSUE
+#undef MSM_COOP_PUT
 }
 
 // Merge run fragments: same walk over the slot sequence of the previous level (keys non-decreasing,
-// KEY_NONE = hole), full XYZZ adds.  Recursion ends when one lane covers everything.
-template <class E>
-__global__ void __launch_bounds__(256) k_segreduce(const XyzzDevT<typename E::T>* __restrict__ in_slots,
+// KEY_NONE = hole), full additions.  Recursion ends when one lane covers everything.
+template <class G>
+__global__ void __launch_bounds__(256) k_segreduce(const XyzzDevT<typename G::T>* __restrict__ in_slots,
                                                    const uint32_t* __restrict__ in_keys, uint32_t n_in, uint32_t K,
-                                                   SegOutT<typename E::T> out, uint32_t nlanes) {
+                                                   SegOutT<typename G::T> out, uint32_t nlanes, uint32_t* __restrict__ flags) {
+  using E = typename G::E;
   const uint32_t t = blockIdx.x * 256 + threadIdx.x;
   if (t >= nlanes) return;
   typename E::Md md;
@@ -162,13 +291,13 @@ __global__ void __launch_bounds__(256) k_segreduce(const XyzzDevT<typename E::T>
   const uint64_t beg = (uint64_t)t * K;
   const uint64_t end = (beg + K < n_in) ? beg + K : n_in;
   uint32_t cur = KEY_NONE;
-  bool first = true;
-  XyzzT<typename E::T> acc;
-  xyzz_set_inf<E>(acc);
+  bool first = true, bad = false;
+  XyzzT<typename G::T> acc;
+  G::set_identity(acc);
   for (uint64_t e = beg; e < end; e++) {
     const uint32_t key = in_keys[e];
     if (key == KEY_NONE) continue;
-    const XyzzDevT<typename E::T> v = in_slots[e];
+    const XyzzDevT<typename G::T> v = in_slots[e];
     if (key != cur) {
       if (cur != KEY_NONE) {
         seg_flush(out, t, nlanes, cur, acc, first, false);
@@ -177,10 +306,12 @@ __global__ void __launch_bounds__(256) k_segreduce(const XyzzDevT<typename E::T>
       cur = key;
       acc = v.p;
     } else {
-      xyzz_add<E>(acc, v.p, md);
+      G::add(acc, v.p, md);
+      if (G::CHECKS) bad |= G::failed(acc);
     }
   }
   if (cur != KEY_NONE) seg_flush(out, t, nlanes, cur, acc, first, true);
+  if (G::CHECKS && bad) flags[1] = 1;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -190,13 +321,14 @@ __global__ void __launch_bounds__(256) k_segreduce(const XyzzDevT<typename E::T>
 //     A'_t = sum A_j + sum (local weight) X_j     and     X'_t = L * sum X_j        (L = 2^logL)
 // so that V = sum_t A'_t + sum_t t * X'_t -- the same problem, L times smaller.  When one chunk is
 // left, V = A'_0.  Running sums walk the chunk from the top: run += X_j; wsum += run.
-template <class E, bool FIRST>
-__global__ void __launch_bounds__(256, E::ACC_WAVES) k_bucket_reduce(const XyzzDevT<typename E::T>* __restrict__ in_a,
-                                                       const XyzzDevT<typename E::T>* __restrict__ in_x,
+template <class G, bool FIRST>
+__global__ void __launch_bounds__(256, G::ACC_WAVES) k_bucket_reduce(const XyzzDevT<typename G::T>* __restrict__ in_a,
+                                                       const XyzzDevT<typename G::T>* __restrict__ in_x,
                                                        uint32_t n_per_win, uint32_t logL, uint32_t chunks_per_win,
-                                                       uint32_t windows, XyzzDevT<typename E::T>* __restrict__ out_a,
-                                                       XyzzDevT<typename E::T>* __restrict__ out_x) {
-  using XD = XyzzDevT<typename E::T>;
+                                                       uint32_t windows, XyzzDevT<typename G::T>* __restrict__ out_a,
+                                                       XyzzDevT<typename G::T>* __restrict__ out_x, uint32_t* __restrict__ flags) {
+  using E = typename G::E;
+  using XD = XyzzDevT<typename G::T>;
   const uint32_t g = blockIdx.x * 256 + threadIdx.x;
   if (g >= windows * chunks_per_win) return;
   typename E::Md md;
@@ -205,29 +337,35 @@ __global__ void __launch_bounds__(256, E::ACC_WAVES) k_bucket_reduce(const XyzzD
   const uint32_t lo = t * L;
   const uint32_t hi = (lo + L < n_per_win) ? lo + L : n_per_win;
   const XD* x = in_x + (size_t)w * n_per_win;
-  XyzzT<typename E::T> run, wsum;
-  xyzz_set_inf<E>(run);
-  xyzz_set_inf<E>(wsum);
+  XyzzT<typename G::T> run, wsum;
+  bool bad = false;
+  G::set_identity(run);
+  G::set_identity(wsum);
   for (uint32_t j = hi; j-- > lo;) {
     const XD v = x[j];
-    xyzz_add<E>(run, v.p, md);
-    if (FIRST || j > lo) xyzz_add<E>(wsum, run, md);
+    G::add(run, v.p, md);
+    if (G::CHECKS) bad |= G::failed(run);
+    if (FIRST || j > lo) {
+      G::add(wsum, run, md);
+      if (G::CHECKS) bad |= G::failed(wsum);
+    }
   }
   if (!FIRST) {
     const XD* a = in_a + (size_t)w * n_per_win;
     for (uint32_t j = lo; j < hi; j++) {
       const XD v = a[j];
-      xyzz_add<E>(wsum, v.p, md);
+      G::add(wsum, v.p, md);
+      if (G::CHECKS) bad |= G::failed(wsum);
     }
   }
-  if (!xyzz_is_inf<E>(run)) {
-    for (uint32_t k = 0; k < logL; k++) xyzz_dbl<E>(run, md);
-  }
+  G::mul_pow2(run, logL, md);
+  if (G::CHECKS) bad |= G::failed(run);
   XD o;
   o.p = wsum;
   out_a[g] = o;
   o.p = run;
   out_x[g] = o;
+  if (G::CHECKS && bad) flags[1] = 1;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -301,6 +439,57 @@ __global__ void __launch_bounds__(256) k_pre_normalize(const XyzzDevT<typename E
     }
     out[j] = o;
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Short-Weierstrass device records -> twisted-Edwards records (te.cuh), Montgomery's trick over J consecutive points per
+// lane: the forward pass stores the running products of the map's denominators, the backward pass peels one inverse per
+// point.  Points without an image are counted in flags[0] (the engine then keeps the base set on the XYZZ path) and get a
+// harmless filler; bases flagged infinite are never gathered.
+template <class F>
+__global__ void __launch_bounds__(256) k_te_convert(const AffineDev* __restrict__ in, const uint8_t* __restrict__ inf, uint32_t n, uint32_t J,
+                                                    Fe* __restrict__ prefix, TeAffineDev* __restrict__ out, uint32_t* __restrict__ flags) {
+  const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+  const uint64_t lo = (uint64_t)t * J;
+  if (lo >= n) return;
+  const uint64_t hi = (lo + J < n) ? lo + J : n;
+  Modulus<F> md;
+  Fe run;
+  fe_set(run, F::ONE);
+  uint32_t bad = 0;
+  for (uint64_t j = lo; j < hi; j++) {
+    prefix[j] = run;
+    if (inf[j]) continue;
+    const AffineDev a = in[j];
+    Fe u, v, w, den;
+    te_map_prepare<F>(u, v, w, den, a.p, md);
+    if (fe_is_zero_M<F>(den))
+      bad++;
+    else
+      fe_mul<F>(run, run, den, md);
+  }
+  Fe inv;
+  fe_inv<F>(inv, run, md);
+  for (uint64_t j = hi; j-- > lo;) {
+    TeAffineDev o;
+    fe_zero(o.p.x);
+    fe_set(o.p.y, F::ONE);
+    fe_zero(o.p.td);
+    if (!inf[j]) {
+      const AffineDev a = in[j];
+      Fe u, v, w, den;
+      te_map_prepare<F>(u, v, w, den, a.p, md);
+      if (!fe_is_zero_M<F>(den)) {
+        Fe ti;
+        const Fe pre = prefix[j];
+        fe_mul<F>(ti, inv, pre, md);      // 1 / den_j
+        fe_mul<F>(inv, inv, den, md);
+        te_map_finish<F>(o.p, u, v, w, ti, md);
+      }
+    }
+    out[j] = o;
+  }
+  if (bad) atomicAdd(&flags[0], bad);
 }
 
 }  // namespace msm

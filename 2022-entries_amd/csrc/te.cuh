@@ -1,0 +1,199 @@
+// te.cuh -- twisted-Edwards image of BLS12-377 G1 in extended coordinates, over fp28.
+//
+// y^2 = x^3 + 1 over the BLS12-377 base field has the rational 2-torsion point (-1, 0) and 3 is a square, so the curve is
+// birationally equivalent to  -X^2 + Y^2 = 1 + d X^2 Y^2  (the "curve isogeny" trick of the Trapdoor-Tech entry,
+// P1A/Trapdoor-Tech/msm_opt.md; extended coordinates as in P1A/Trapdoor-Tech/sppark/ec/exte_t.hpp):
+//     u = S (x + 1), v = S y  (S = 1/sqrt 3)        X = FSC u / v,  Y = (u - 1)/(u + 1)
+// A mixed addition is 7 multiplications (EFD madd-2008-hwcd-3 with the 2d factor folded into the base record) against 8M + 2S
+// for XYZZ, there is no doubling / infinity / cancellation branch (the law is unified and the identity (0, 1) is an ordinary
+// point), and a full addition is 9M against 12M + 2S.  The constants are derived in oracle/te_model.py.
+//
+// Caveats, both handled by the engine rather than assumed away:
+//   * five curve points have no image (the three 2-torsion points and the two points with u = -1): the base converter
+//     counts them and a base set that contains one stays on the short-Weierstrass path;
+//   * d is a SQUARE mod p, so the law is complete only on odd-order subgroups (every input of the harness lies in the
+//     r-torsion).  Off the subgroup an addition can hit a vanishing denominator, which shows as Z3 = 0: every kernel
+//     checks it after each addition and raises a flag, and the engine then repeats the run on the XYZZ path.
+//
+// Extended points reuse XyzzT<Fe>: x = X, y = Y, zz = Z, zzz = T with X Y = Z T; all four are class M (strictly normalized
+// limbs, value < 1.5p).  Base records hold (X, Y, 2 d X Y), canonical.
+#pragma once
+#include "curve.cuh"
+
+namespace msm {
+
+struct TeAffine {
+  Fe x, y, td;
+};
+// 168 B padded to three 64-B sectors, so one lane's gather touches exactly three
+struct alignas(64) TeAffineDev {
+  TeAffine p;
+};
+static_assert(sizeof(TeAffineDev) == 192, "device twisted-Edwards base layout");
+
+template <class F>
+MSM_HD void te_set_identity(Xyzz& r) {
+  fe_zero(r.x);
+  fe_set(r.y, F::ONE);
+  fe_set(r.zz, F::ONE);
+  fe_zero(r.zzz);
+}
+
+// An addition whose denominator vanished leaves Z = 0 (valid points never have Z = 0).
+template <class F>
+MSM_HD bool te_failed(const Xyzz& a) {
+  return fe_is_zero_M<F>(a.zz);
+}
+
+// r = (+/-) base as an extended point with Z = 1: one multiplication (T = X Y).  -X is made canonical again so the result
+// obeys the stored-point contract (the slow exact reduction runs once per bucket run, not per addition).
+template <class F>
+MSM_HD void te_from_affine(Xyzz& r, const TeAffine& b, bool negate, const Modulus<F>& md) {
+  Fe nx, x = b.x;
+  fe_neg(nx, b.x, F::BIAS2_28);   // (p, 2p], limbs < 2^29
+  fe_reduce<F>(nx);               // [0, p)
+  fe_cmov(x, nx, negate);
+  r.x = x;
+  r.y = b.y;
+  fe_set(r.zz, F::ONE);
+  fe_mul<F>(r.zzz, x, b.y, md);
+}
+
+// Shared tail: from A, B, C (class M) and D (limbs < 2^29, value < 3p) produce the sum.
+//   E = B - A, F = D - C, G = D + C, H = B + A;  X3 = E F, Y3 = G H, T3 = E H, Z3 = F G.
+template <class F>
+MSM_HD void te_tail(Xyzz& r, const Fe& A, const Fe& B, const Fe& C, const Fe& D, const Modulus<F>& md) {
+  Fe e, f, g, h;
+  fe_sub(e, B, A, F::BIAS2_28);   // (0.5p, 3.5p), limbs < 2^28 + 2^29
+  fe_sub(f, D, C, F::BIAS2_28);   // (0.5p, 5p),   limbs < 2^29 + 2^29
+  fe_add(g, D, C);                // < 4.5p,       limbs < 2^29 + 2^28
+  fe_add(h, B, A);                // < 3p,         limbs < 2^29
+  fe_mul<F>(r.x, e, f, md);       // 3.5p * 5p
+  fe_mul<F>(r.y, g, h, md);
+  fe_mul<F>(r.zzz, e, h, md);
+  fe_mul<F>(r.zz, f, g, md);      // 5p * 4.5p < 2^10 p^2
+}
+
+// acc += (+/-) base   (7M).  -(X, Y) = (-X, Y): Y - X and Y + X trade places and 2dXY changes sign.
+template <class F>
+MSM_HD void te_madd(Xyzz& acc, const TeAffine& b, bool negate, const Modulus<F>& md) {
+  Fe ymx, ypx, t, td, ntd;
+  fe_sub(ymx, b.y, b.x, F::BIAS2_28);   // (p, 3p), limbs < 2^28 + 2^29
+  fe_add(ypx, b.y, b.x);                // < 2p,    limbs < 2^29
+  t = ymx;
+  fe_cmov(ymx, ypx, negate);
+  fe_cmov(ypx, t, negate);
+  fe_neg(ntd, b.td, F::BIAS2_28);       // (p, 2p], limbs < 2^29
+  td = b.td;
+  fe_cmov(td, ntd, negate);
+  Fe a1, b1, A, B, C, D;
+  fe_sub(a1, acc.y, acc.x, F::BIAS2_28);   // (0, 4p), limbs < 2^28 + 2^29
+  fe_add(b1, acc.y, acc.x);                // < 4p,    limbs < 2^29
+  fe_mul<F>(A, a1, ymx, md);               // 4p * 3p
+  fe_mul<F>(B, b1, ypx, md);
+  fe_mul<F>(C, acc.zzz, td, md);
+  fe_dbl(D, acc.zz);                       // < 3p, limbs < 2^29
+  te_tail<F>(acc, A, B, C, D, md);
+}
+
+// acc += b, both extended (9M: add-2008-hwcd-3 with k = 2d).  Unified: b may equal acc.
+template <class F>
+MSM_HD void te_add(Xyzz& acc, const Xyzz& b, const Modulus<F>& md) {
+  Fe a1, a2, b1, b2, A, B, C, D, kt, zz, k;
+  fe_sub(a1, acc.y, acc.x, F::BIAS2_28);   // (0, 4p)
+  fe_sub(a2, b.y, b.x, F::BIAS2_28);
+  fe_add(b1, acc.y, acc.x);                // < 4p
+  fe_add(b2, b.y, b.x);
+  fe_set(k, Bls12_377_Te::K2D);
+  fe_mul<F>(kt, b.zzz, k, md);
+  fe_mul<F>(zz, acc.zz, b.zz, md);
+  fe_mul<F>(A, a1, a2, md);                // 4p * 4p
+  fe_mul<F>(B, b1, b2, md);
+  fe_mul<F>(C, acc.zzz, kt, md);
+  fe_dbl(D, zz);
+  te_tail<F>(acc, A, B, C, D, md);
+}
+
+template <class F>
+MSM_HD void te_dbl(Xyzz& acc, const Modulus<F>& md) {
+  const Xyzz b = acc;
+  te_add<F>(acc, b, md);
+}
+
+// ---- the birational map ---------------------------------------------------------------------------------------
+// SW affine (canonical coordinates) -> what the image needs:  u = S (x + 1), v = S y, w = u + 1, den = v w.
+// den == 0 (mod p) <=> the point has no image (y = 0: the three 2-torsion points; u = -1: two more points).
+template <class F>
+MSM_HD void te_map_prepare(Fe& u, Fe& v, Fe& w, Fe& den, const Affine& p, const Modulus<F>& md) {
+  Fe s, one, xp1;
+  fe_set(s, Bls12_377_Te::S);
+  fe_set(one, F::ONE);
+  fe_add(xp1, p.x, one);          // < 2.5p, limbs < 2^29
+  fe_mul<F>(u, s, xp1, md);
+  fe_mul<F>(v, s, p.y, md);
+  fe_add(w, u, one);              // < 3p, limbs < 2^29
+  fe_mul<F>(den, v, w, md);
+}
+
+// With inv = 1/den:  X = FSC u w inv,  Y = (u - 1) v inv,  TD = 2d X Y; all canonical.
+template <class F>
+MSM_HD void te_map_finish(TeAffine& out, const Fe& u, const Fe& v, const Fe& w, const Fe& inv, const Modulus<F>& md) {
+  Fe t, c, one, um1;
+  fe_set(one, F::ONE);
+  fe_mul<F>(t, u, w, md);
+  fe_mul<F>(t, t, inv, md);
+  fe_set(c, Bls12_377_Te::FSC);
+  fe_mul<F>(out.x, t, c, md);
+  fe_sub(um1, u, one, F::BIAS2_28);   // (0.5p, 3.5p), limbs < 2^28 + 2^29
+  fe_mul<F>(t, um1, v, md);
+  fe_mul<F>(out.y, t, inv, md);
+  fe_mul<F>(t, out.x, out.y, md);
+  fe_set(c, Bls12_377_Te::K2D);
+  fe_mul<F>(out.td, t, c, md);
+  fe_reduce<F>(out.x);
+  fe_reduce<F>(out.y);
+  fe_reduce<F>(out.td);
+}
+
+// Extended twisted-Edwards point -> short-Weierstrass XYZZ (affine, ZZ = ZZZ = 1).  One inversion: host side / rare.
+//   u = (Z + Y)/(Z - Y),  v = FSC u Z / X;   x = sqrt3 u - 1,  y = sqrt3 v.
+// (0, 1) is the identity -> infinity; (0, -1) is the image of the 2-torsion point (-1, 0).  The caller has checked Z != 0.
+template <class F>
+MSM_HD void te_to_sw(Xyzz& out, const Xyzz& a, const Modulus<F>& md) {
+  using E = FpEl<F>;
+  Fe one;
+  fe_set(one, F::ONE);
+  if (fe_is_zero_M<F>(a.x)) {
+    Fe d;
+    fe_sub(d, a.y, a.zz, F::BIAS2_28);
+    if (fe_is_zero_slow<F>(d)) {
+      xyzz_set_inf<E>(out);
+    } else {
+      fe_neg(out.x, one, F::BIAS2_28);
+      fe_reduce<F>(out.x);
+      fe_zero(out.y);
+      out.zz = one;
+      out.zzz = one;
+    }
+    return;
+  }
+  Fe n, dn, den, inv, t, c;
+  fe_add(n, a.zz, a.y);                     // < 3p, limbs < 2^29
+  fe_sub(dn, a.zz, a.y, F::BIAS2_28);       // (0.5p, 3.5p)
+  fe_mul<F>(den, dn, a.x, md);
+  fe_inv<F>(inv, den, md);
+  fe_mul<F>(t, n, a.x, md);
+  fe_mul<F>(t, t, inv, md);                 // u
+  fe_set(c, Bls12_377_Te::SQRT3);
+  fe_mul<F>(t, t, c, md);
+  fe_sub(out.x, t, one, F::BIAS2_28);       // (0.5p, 3.5p)
+  fe_carry(out.x);
+  fe_mul<F>(t, n, a.zz, md);
+  fe_mul<F>(t, t, inv, md);                 // u Z / X
+  fe_set(c, Bls12_377_Te::FSC_SQRT3);
+  fe_mul<F>(out.y, t, c, md);
+  out.zz = one;
+  out.zzz = one;
+}
+
+}  // namespace msm

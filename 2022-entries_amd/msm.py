@@ -87,6 +87,7 @@ def load_library() -> ctypes.CDLL:
         "mi355_msm_run_device": [vp, vp, vp, sz, sz, vp],
         "mi355_msm_set_option": [vp, ctypes.c_char_p, ctypes.c_long],
         "mi355_msm_last_timings": [vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_uint64)],
+        "mi355_msm_query": [vp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_uint64)],
         "mi355_msm": [ci, vp, vp, sz, vp, sz],
         "mi355_msm_fold": [ci, vp, vp, sz],
         "mi355_msm_generate_points": [ci, ctypes.c_uint64, sz, sz, vp, sz],
@@ -216,6 +217,12 @@ class MultiScalarMultContext:
 
     def set_option(self, key: str, value: int) -> None:
         _check(self._lib.mi355_msm_set_option(self.context, key.encode(), int(value)))
+
+    def query(self, key: str) -> int:
+        """Context state: "twisted_edwards", "twisted_edwards_fallbacks", "bases", "table_levels", "table_window_bits", "base_bytes"."""
+        v = ctypes.c_uint64(0)
+        _check(self._lib.mi355_msm_query(self.context, key.encode(), ctypes.byref(v)))
+        return int(v.value)
 
     def last_timings(self) -> dict:
         ms = (ctypes.c_float * 8)()

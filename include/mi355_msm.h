@@ -105,6 +105,17 @@ RustError mi355_msm_run_device(mi355_msm_ctx* ctx, void* out_projective, const v
  * (ARK ec/src/msm/variable_base/mod.rs:48-53; sppark's `mont` flag SPK msm/pippenger.cuh:157-164).
  * Mirrors Matter Labs' runtime msm_configuration (P1A matter-labs/.../bellman-cuda.h:49-71). */
 RustError mi355_msm_set_option(mi355_msm_ctx* ctx, const char* key, long value);
+/* "twisted_edwards" (default 1; set BEFORE set_bases; BLS12-377 G1 only) lets the context keep, next to the bases, their image on
+ * the birationally equivalent twisted Edwards curve -X^2 + Y^2 = 1 + d X^2 Y^2 and accumulate there: 7 field multiplications
+ * per mixed addition instead of 8M + 2S, no doubling/infinity branches (the trick of P1A Trapdoor-Tech/msm_opt.md and of the FPGA
+ * entries).  Results are identical BY CONSTRUCTION, not by assumption: a base set containing one of the five points without
+ * an image (e.g. the FPGA harness's 2-torsion fixture) stays on the short-Weierstrass path, and because d is a square the
+ * kernels check every addition for a vanishing denominator (possible only for inputs outside the prime-order subgroup) and
+ * the run is then repeated on the short-Weierstrass path.  Costs 192 B per base (per table level) of HBM on top. */
+/* State of a context: "twisted_edwards" (1 = the current bases run on the twisted-Edwards path), "twisted_edwards_fallbacks"
+ * (runs repeated on the XYZZ path so far), "bases", "table_levels", "table_window_bits", "base_bytes" (device bytes held
+ * for the bases). */
+RustError mi355_msm_query(mi355_msm_ctx* ctx, const char* key, uint64_t* value);
 /* Per-stage device time (ms, HIP events on the launch stream) of the most recent run, summed over its chunks
  * and batches; ms must hold MI355_T_COUNT floats.  info: [0]=window bits, [1]=windows, [2]=sorted entries of the
  * last chunk, [3]=entries per lane, [4]=accumulate launches, [5]=lanes of the last launch. */

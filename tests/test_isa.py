@@ -19,8 +19,8 @@ HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
 def test_accumulate_kernel_isa():
     src = '#include "%s/2022-entries_amd/csrc/msm_kernels.cuh"\nnamespace msm {\n' \
-          'template __global__ void k_accumulate<FpEl<Bls12_377_Fq>>(const uint32_t*, const uint32_t*, uint32_t, uint32_t, uint32_t, ' \
-          'const AffineDev*, SegOut, uint32_t);\n}\n' % ROOT
+          'template __global__ void k_accumulate<SwLaw<FpEl<Bls12_377_Fq>>>(const uint32_t*, const uint32_t*, uint32_t, uint32_t, uint32_t, ' \
+          'const AffineDev*, SegOut, uint32_t, uint32_t*);\n}\n' % ROOT
     with tempfile.TemporaryDirectory() as d:
         open(os.path.join(d, "acc.hip"), "w").write(src)
         r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++20", "-c", "acc.hip", "-o", "acc.o", "-save-temps",
