@@ -24,7 +24,9 @@ struct SwLaw {
   static constexpr bool CHECKS = false;
   static constexpr int ACC_WAVES = E::ACC_WAVES;
   static constexpr bool PREFETCH_BASE = E::PREFETCH_BASE;
-  static constexpr bool COOP_GATHER = false;
+  // quad-cooperative gathers (k_accumulate_coop) for 128-B records: slots padded to 144 B against LDS bank conflicts
+  static constexpr bool COOP_GATHER = sizeof(BaseDev) == 128;
+  static constexpr int COOP_LDS_STRIDE = 144;
   static MSM_HD void set_identity(XyzzT<T>& r) { xyzz_set_inf<E>(r); }
   static MSM_HD void madd(XyzzT<T>& acc, const Base& b, bool negate, bool fresh, const Md& md) { xyzz_madd<E>(acc, b, negate, fresh, md); }
   static MSM_HD void add(XyzzT<T>& acc, const XyzzT<T>& b, const Md& md) { xyzz_add<E>(acc, b, md); }

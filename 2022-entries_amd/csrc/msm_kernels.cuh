@@ -202,7 +202,7 @@ __global__ void __launch_bounds__(256, G::ACC_WAVES) k_accumulate_coop(const uin
 
   // The quad's four gathers: record i belongs to quad lane i; a lane without a next entry asks for record 0.
   // (Twelve named registers and macros rather than an array and lambdas: hipcc leaves a loop-carried array in scratch.)
-  static_assert(SECT == 3, "the piece registers below are written out for three-sector records");
+  static_assert(SECT == 2 || SECT == 3, "the piece registers below are written out for two- and three-sector records");
   uint4 q00, q01, q02, q10, q11, q12, q20, q21, q22, q30, q31, q32;
 #define MSM_COOP_ISSUE(val, valid)                                                                                      \
   do {                                                                                                                  \
@@ -211,10 +211,13 @@ __global__ void __launch_bounds__(256, G::ACC_WAVES) k_accumulate_coop(const uin
     const uint4* s1_ = reinterpret_cast<const uint4*>(bases + (uint32_t)__builtin_amdgcn_update_dpp(0, mine_, 0x55, 0xf, 0xf, true)) + sub; \
     const uint4* s2_ = reinterpret_cast<const uint4*>(bases + (uint32_t)__builtin_amdgcn_update_dpp(0, mine_, 0xaa, 0xf, 0xf, true)) + sub; \
     const uint4* s3_ = reinterpret_cast<const uint4*>(bases + (uint32_t)__builtin_amdgcn_update_dpp(0, mine_, 0xff, 0xf, 0xf, true)) + sub; \
-    q00 = s0_[0]; q01 = s0_[4]; q02 = s0_[8];                                                                           \
-    q10 = s1_[0]; q11 = s1_[4]; q12 = s1_[8];                                                                           \
-    q20 = s2_[0]; q21 = s2_[4]; q22 = s2_[8];                                                                           \
-    q30 = s3_[0]; q31 = s3_[4]; q32 = s3_[8];                                                                           \
+    q00 = s0_[0]; q01 = s0_[4];                                                                                         \
+    q10 = s1_[0]; q11 = s1_[4];                                                                                         \
+    q20 = s2_[0]; q21 = s2_[4];                                                                                         \
+    q30 = s3_[0]; q31 = s3_[4];                                                                                         \
+    if (SECT == 3) {                                                                                                    \
+      q02 = s0_[8]; q12 = s1_[8]; q22 = s2_[8]; q32 = s3_[8];                                                           \
+    }                                                                                                                   \
   } while (0)
 #define MSM_COOP_PUT(i, c, reg) *reinterpret_cast<uint4*>(quad_slots + (i) * LS + (c) * 64 + sub * 16) = reg
 
@@ -229,10 +232,13 @@ __global__ void __launch_bounds__(256, G::ACC_WAVES) k_accumulate_coop(const uin
     Base p;
     {
       unsigned char* quad_slots = lds + (threadIdx.x & ~3u) * LS;
-      MSM_COOP_PUT(0, 0, q00); MSM_COOP_PUT(0, 1, q01); MSM_COOP_PUT(0, 2, q02);
-      MSM_COOP_PUT(1, 0, q10); MSM_COOP_PUT(1, 1, q11); MSM_COOP_PUT(1, 2, q12);
-      MSM_COOP_PUT(2, 0, q20); MSM_COOP_PUT(2, 1, q21); MSM_COOP_PUT(2, 2, q22);
-      MSM_COOP_PUT(3, 0, q30); MSM_COOP_PUT(3, 1, q31); MSM_COOP_PUT(3, 2, q32);
+      MSM_COOP_PUT(0, 0, q00); MSM_COOP_PUT(0, 1, q01);
+      MSM_COOP_PUT(1, 0, q10); MSM_COOP_PUT(1, 1, q11);
+      MSM_COOP_PUT(2, 0, q20); MSM_COOP_PUT(2, 1, q21);
+      MSM_COOP_PUT(3, 0, q30); MSM_COOP_PUT(3, 1, q31);
+      if (SECT == 3) {
+        MSM_COOP_PUT(0, 2, q02); MSM_COOP_PUT(1, 2, q12); MSM_COOP_PUT(2, 2, q22); MSM_COOP_PUT(3, 2, q32);
+      }
       const uint4* mine = reinterpret_cast<const uint4*>(lds + threadIdx.x * LS);
       uint32_t* dst = reinterpret_cast<uint32_t*>(&p);
 #pragma unroll
