@@ -190,13 +190,15 @@ def main():
             "data": "synthetic: 2^15 distinct subgroup points replicated (reference generator shape), uniform scalars < r",
             "config": {"workload": f"{args.curve} MSM, 2^{args.npow} pairs per GPU, bases+scalars resident in HBM",
                        "pairs_per_gpu": n, "window_bits": tm["window_bits"], "windows": tm["windows"],
-                       "lane_entries": tm["lane_entries"], "precompute": bool(args.precompute), "init_s": t_init, "parallelism": f"{world} disjoint base/scalar slices + all-gather of {world} partial points"},
+                       "lane_entries": tm["lane_entries"], "precompute": bool(args.precompute),
+                       "group_law": "extended twisted Edwards (7M mixed add)" if ctx.query("twisted_edwards") else "XYZZ (8M+2S mixed add)",
+                       "init_s": t_init, "parallelism": f"{world} disjoint base/scalar slices + all-gather of {world} partial points"},
             "stage_ms_per_step": {k: v / args.steps for k, v in stage_ms.items()},
-            "roofline": {"bound": "hbm", "kernel": "k_accumulate", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "k_accumulate" if cid == 2 else "k_accumulate_coop", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "kernel_ms": kern_s * 1e3, "algorithmic_bytes_per_launch": BYTES_PER_PAIR[cid] * pairs_per_launch,
                          "valu": valu,
-                         "note": "integer-VALU-bound path (no MFMA): the binding resource is VALU issue (DESIGN.md section 5)"},
+                         "note": "integer-VALU-bound path (no MFMA): the binding resource is VALU issue at the power-limited clock (DESIGN.md section 5)"},
         }
         if world == 1 and args.cpu_sample_pow > 0:
             sample = min(n, 1 << args.cpu_sample_pow)
