@@ -74,8 +74,18 @@ struct TeLaw {
     if (fe_is_zero_M<F>(b.zz)) return;
     te_add<F>(acc, b, md);
   }
+  // A doubling that fails leaves Z = 0, but doubling THAT again gives Z = -(2d T^2)^2, which need not be 0: the failure is
+  // frozen by zeroing the point (all-zero stays all-zero under the law), so the caller's single check after the loop sees it.
   static MSM_HD void mul_pow2(Xyzz& acc, uint32_t k, const Md& md) {
-    for (uint32_t i = 0; i < k; i++) te_dbl<F>(acc, md);
+    for (uint32_t i = 0; i < k; i++) {
+      te_dbl<F>(acc, md);
+      if (te_failed<F>(acc)) {
+        fe_zero(acc.x);
+        fe_zero(acc.y);
+        fe_zero(acc.zz);
+        fe_zero(acc.zzz);
+      }
+    }
   }
   static MSM_HD bool failed(const Xyzz& a) { return te_failed<F>(a); }
 };
