@@ -220,6 +220,7 @@ def main():
         if world == 1 and args.also_precompute and not args.precompute and cid != 2:
             # the reference's own convention (init untimed, tables built there): reported next to the headline, not as it
             try:
+                ctx.close()   # give the headline context's ~40 GB back before the tables (95 + 142 GB while they are converted)
                 ctx2 = ea.MultiScalarMultContext(args.curve, device=local_rank)
                 ctx2.set_option("precompute", 1)
                 t_i = time.perf_counter()
