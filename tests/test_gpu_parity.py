@@ -429,5 +429,13 @@ def test_full_size_properties(ea, oracle, torch_cuda, cid, curve, npow):
         host = torch.cat([as_bytes(k1), as_bytes(k2)]).cpu().numpy()
         assert ctx.run(host) == [r1, r2]
         assert ctx.last_timings()["launches"] == 3          # 2 chunks for batch 0, 1 for batch 1
+    # (9) BLS12-377: the twisted-Edwards path (default) and the XYZZ path agree at full size
+    if cid == 0:
+        assert ctx.query("twisted_edwards") == 1 and ctx.query("twisted_edwards_fallbacks") == 0
+        ctx_sw = ea.MultiScalarMultContext(curve.name)
+        ctx_sw.set_option("twisted_edwards", 0)
+        ctx_sw.set_bases(bases)
+        assert ctx_sw.query("twisted_edwards") == 0 and ctx_sw.run(as_bytes(k1))[0] == r1
+        ctx_sw.close()
     ctx.close()
     ctx_hi.close()
