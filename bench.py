@@ -9,7 +9,7 @@ AND the scalars already resident in HBM: device scalars -> digits -> sort -> buc
 window sums to the host -> Horner fold; with N > 1 ranks each rank owns a disjoint slice (weak scaling: 2^npow pairs
 per GPU), the N 144-byte partials are all-gathered with RCCL and folded on every rank.  Rank 0 prints ONE JSON line.
 
-`roofline` is for the dominant kernel (bucket accumulation, k_accumulate): algorithmic bytes = 128 B/pair
+`roofline` is for the dominant kernel (bucket accumulation, k_accumulate_coop): algorithmic bytes = 128 B/pair
 (32 B scalar + 96 B affine base) x pairs per launch, over its HIP-event duration on the launch stream.
 `cpu_baseline` times oracle/liboracle.so -- the C restatement of arkworks' VariableBaseMSM, one thread per window like
 rayon -- on a bounded sample of the same workload, rank 0, N = 1 only.  It is a reported baseline, not the target.
@@ -23,6 +23,8 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# the host driver only supports dmabuf IPC: without this RCCL's cross-process buffer sharing fails (hipIpcGetMemHandle)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 BYTES_PER_PAIR = {0: 128.0, 1: 128.0, 2: 224.0}   # 32 B scalar + 96 B affine base (G2: + 192 B)
