@@ -270,22 +270,17 @@ int ht_te_map(const uint8_t* img, uint8_t* out) {
   memcpy(out, w, 144);
   return 0;
 }
-// sum of (+/-) points through te_from_affine (first) and te_madd (rest), mapped back: a Projective image.
+// sum of (+/-) points through te_madd, starting from the identity as the kernels do, mapped back: a Projective image.
 // 1 = a point without image, 2 = an addition hit a vanishing denominator (Z = 0).
 int ht_te_madd_chain(const uint8_t* pts, size_t stride, const uint8_t* neg, size_t n, uint8_t* out) {
   Modulus<TF> md;
   Xyzz acc;
   te_set_identity<TF>(acc);
-  bool fresh = true;
   for (size_t i = 0; i < n; i++) {
     if (pts[i * stride + 96]) continue;
     TeAffine t;
     if (!te_map_host(t, pts + i * stride, md)) return 1;
-    if (fresh)
-      te_from_affine<TF>(acc, t, neg[i] != 0, md);
-    else
-      te_madd<TF>(acc, t, neg[i] != 0, md);
-    fresh = false;
+    te_madd<TF>(acc, t, neg[i] != 0, md);
     if (te_failed<TF>(acc)) return 2;
   }
   return te_finish_host(out, acc, md);

@@ -4,7 +4,7 @@
 //   TeLaw<F>  twisted-Edwards image of BLS12-377 G1, extended accumulators, (X, Y, 2dXY)   -- the fast path (te.cuh)
 //
 // Interface:  Point (always XyzzT<T>: the 4-coordinate accumulator, so slots/buckets/fragments share one layout),
-//   Base/BaseDev (what a lane gathers), set_identity, madd(acc, base, negate, fresh), add(acc, b) where b may be an
+//   Base/BaseDev (what a lane gathers), set_identity, begin_run(acc) at every change of key, madd(acc, base, negate, fresh), add(acc, b) where b may be an
 //   all-zero "empty" record (a bucket nobody wrote), mul_pow2(acc, k), and failed(acc): true when the law could not
 //   compute the last result (TeLaw only: a vanishing denominator off the odd-order subgroup) -- kernels raise a flag then.
 #pragma once
@@ -28,6 +28,7 @@ struct SwLaw {
   static constexpr bool COOP_GATHER = sizeof(BaseDev) == 128;
   static constexpr int COOP_LDS_STRIDE = 144;
   static MSM_HD void set_identity(XyzzT<T>& r) { xyzz_set_inf<E>(r); }
+  static MSM_HD void begin_run(XyzzT<T>&) {}   // XYZZ: the `fresh` flag makes the first madd a copy
   static MSM_HD void madd(XyzzT<T>& acc, const Base& b, bool negate, bool fresh, const Md& md) { xyzz_madd<E>(acc, b, negate, fresh, md); }
   static MSM_HD void add(XyzzT<T>& acc, const XyzzT<T>& b, const Md& md) { xyzz_add<E>(acc, b, md); }
   static MSM_HD void mul_pow2(XyzzT<T>& acc, uint32_t k, const Md& md) {
@@ -60,15 +61,9 @@ struct TeLaw {
   static MSM_HD void set_identity(Xyzz& r) { te_set_identity<F>(r); }
   // A run's first element is added onto the identity through the same 7M formula: a cheaper "copy" branch would be taken by
   // some lane of a wave at most positions (runs are ~64 entries long), so the whole wave would pay for both paths.
-  static MSM_HD void madd(Xyzz& acc, const Base& b, bool negate, bool fresh, const Md& md) {
-    Xyzz id;
-    te_set_identity<F>(id);
-    fe_cmov(acc.x, id.x, fresh);
-    fe_cmov(acc.y, id.y, fresh);
-    fe_cmov(acc.zz, id.zz, fresh);
-    fe_cmov(acc.zzz, id.zzz, fresh);
-    te_madd<F>(acc, b, negate, md);
-  }
+  // The accumulator is reset in begin_run (a handful of moves under the run-change branch the walk has anyway).
+  static MSM_HD void begin_run(Xyzz& acc) { te_set_identity<F>(acc); }
+  static MSM_HD void madd(Xyzz& acc, const Base& b, bool negate, bool /*fresh*/, const Md& md) { te_madd<F>(acc, b, negate, md); }
   // Z = 0 never occurs in a valid point: it marks an empty (zero-filled) bucket, which adds nothing.
   static MSM_HD void add(Xyzz& acc, const Xyzz& b, const Md& md) {
     if (fe_is_zero_M<F>(b.zz)) return;

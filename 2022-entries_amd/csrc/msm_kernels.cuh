@@ -147,6 +147,7 @@ __global__ void __launch_bounds__(256, G::ACC_WAVES) k_accumulate(const uint32_t
       }
       cur = key;
       fresh = true;
+      G::begin_run(acc);
     }
     G::madd(acc, p, (val >> 31) != 0, fresh, md);
     if (G::CHECKS) bad |= G::failed(acc);
@@ -270,6 +271,7 @@ __global__ void __launch_bounds__(256, G::ACC_WAVES) k_accumulate_coop(const uin
         }
         cur = key;
         fresh = true;
+        G::begin_run(acc);
       }
       G::madd(acc, p, (val >> 31) != 0, fresh, md);
       if (G::CHECKS) bad |= G::failed(acc);

@@ -45,20 +45,6 @@ MSM_HD bool te_failed(const Xyzz& a) {
   return fe_is_zero_M<F>(a.zz);
 }
 
-// r = (+/-) base as an extended point with Z = 1: one multiplication (T = X Y).  -X is made canonical again so the result
-// obeys the stored-point contract (the slow exact reduction runs once per bucket run, not per addition).
-template <class F>
-MSM_HD void te_from_affine(Xyzz& r, const TeAffine& b, bool negate, const Modulus<F>& md) {
-  Fe nx, x = b.x;
-  fe_neg(nx, b.x, F::BIAS2_28);   // (p, 2p], limbs < 2^29
-  fe_reduce<F>(nx);               // [0, p)
-  fe_cmov(x, nx, negate);
-  r.x = x;
-  r.y = b.y;
-  fe_set(r.zz, F::ONE);
-  fe_mul<F>(r.zzz, x, b.y, md);
-}
-
 // Shared tail: from A, B, C (class M) and D (limbs < 2^29, value < 3p) produce the sum.
 //   E = B - A, F = D - C, G = D + C, H = B + A;  X3 = E F, Y3 = G H, T3 = E H, Z3 = F G.
 template <class F>

@@ -63,7 +63,7 @@ def test_map_matches_model_and_flags_exceptional_points(ht):
 
 
 def test_mixed_add_chain_every_case(ht):
-    """first element (copy), general add, P + P through the unified formula, P - P -> identity -> continues, negated bases,
+    """first element (added onto the identity), general add, P + P through the unified formula, P - P -> identity -> continues, negated bases,
     bases flagged infinite, a result equal to the identity."""
     rng = random.Random(3)
     pts = m.random_points(C, 10, rng)
