@@ -175,6 +175,13 @@ def main():
             traffic = pmc["traffic_bytes_raw"]
             valu = {"busy_fraction": pmc["derived"]["valu_busy_fraction"], "effective_clock_GHz": pmc["derived"]["effective_clock_GHz"],
                     "valu_instr_per_mixed_add": pmc["derived"]["valu_instr_per_mixed_add"], "source": "profiles/r01_pmc_k_accumulate.json"}
+        # the integer roofline: lane-level v_mad_u64_u32 per second in the dominant kernel against the measured
+        # issue peak of 1024 SIMDs x 64 lanes / 4.3 cycles at the nominal 2.4 GHz (profiles/r01_ubench_valu_*.txt)
+        te_path = bool(ctx.query("twisted_edwards"))
+        mads_per_add = {0: 2646 if te_path else 3416, 1: 3542, 2: 11584}[cid]
+        adds_per_launch = tm["entries"]          # one mixed addition per sorted entry (zero digits are a ~1e-6 fraction)
+        mad_rate = mads_per_add * adds_per_launch / kern_s
+        mad_peak = 1024 * 64 / 4.3 * 2.4e9
         out = {
             "metric": {0: "BLS12-377 G1", 1: "BLS12-381 G1", 2: "BLS12-377 G2"}[cid] + " MSM point-scalar pairs/s",
             "value": value,
@@ -200,6 +207,9 @@ def main():
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "kernel_ms": kern_s * 1e3, "algorithmic_bytes_per_launch": BYTES_PER_PAIR[cid] * pairs_per_launch,
                          "valu": valu,
+                         "integer": {"mads_per_mixed_add": mads_per_add, "lane_mads_per_s": mad_rate, "peak_lane_mads_per_s": mad_peak,
+                                     "frac": mad_rate / mad_peak,
+                                     "peak_is": "v_mad_u64_u32 issue limit at the nominal 2.4 GHz; the kernel runs power-limited near 1.9 GHz"},
                          "note": "integer-VALU-bound path (no MFMA): the binding resource is VALU issue at the power-limited clock (DESIGN.md section 5)"},
         }
         if world == 1 and args.cpu_sample_pow > 0:
