@@ -142,6 +142,7 @@ struct mi355_msm_ctx {
   hipEvent_t ev[8] = {};
   long opt_window_bits = 0, opt_lane_entries = 0, opt_max_chunk = 0, opt_seg_entries = 0, opt_scalars_montgomery = 0;
   long opt_precompute = 0;
+  long opt_reduce_log_chunk = 0;
   long opt_twisted_edwards = 1;   // BLS12-377 G1 only: accumulate on the twisted-Edwards image when every base has one
   // twisted-Edwards fast path (te.cuh): records for every table level; te_active is decided per base set
   DevBuf te_bases, flags;         // flags: u32[2] on the device, [0] bases without an image, [1] an addition failed
@@ -178,9 +179,11 @@ struct mi355_msm_ctx {
     p.segK = opt_seg_entries >= 4 ? (uint32_t)opt_seg_entries : 8;
     uint64_t nb = (uint64_t)p.bucket_windows * p.half;
     uint32_t l0 = nb > (1u << 18) ? ilog2_floor(nb >> 18) : 0;
-    p.logL0 = std::min<uint32_t>(7, std::max<uint32_t>(3, l0));
+    // chunks of 4 on the later (small, latency-bound) levels and on small inputs: -7 % wall at 2^14..2^18 against chunks of 8
+    p.logL0 = std::min<uint32_t>(7, std::max<uint32_t>(2, l0));
+    p.logL = 2;
+    if (opt_reduce_log_chunk) p.logL0 = p.logL = (uint32_t)opt_reduce_log_chunk;
     p.logL0 = std::min<uint32_t>(p.logL0, p.c - 1 ? p.c - 1 : 1);
-    p.logL = 3;
     p.T0 = ceil_div(p.half, 1u << p.logL0);
     return p;
   }
@@ -774,6 +777,9 @@ RustError mi355_msm_set_option(mi355_msm_ctx* ctx, const char* key, long value) 
       // fan-in K maps n slots to 2*ceil(n/K); that only shrinks for K >= 4
       if (value != 0 && (value < 4 || value > 4096)) bad_arg("seg_entries %ld out of range [4, 4096]", value);
       ctx->opt_seg_entries = value;
+    } else if (k == "reduce_log_chunk") {
+      if (value < 0 || value > 7) bad_arg("reduce_log_chunk %ld out of range [1, 7]", value);
+      ctx->opt_reduce_log_chunk = value;
     } else if (k == "twisted_edwards") {
       ctx->opt_twisted_edwards = value != 0;   // takes effect at the next set_bases
     } else if (k == "precompute") {
