@@ -1,4 +1,4 @@
-// curve.cuh -- short-Weierstrass (a = 0) group law in extended-Jacobian XYZZ coordinates over fp28.
+// curve.hpp -- short-Weierstrass (a = 0) group law in extended-Jacobian XYZZ coordinates over fp28.
 //
 // x = X/ZZ, y = Y/ZZZ, ZZ^3 = ZZZ^2.  Formulas are the public EFD ones the reference entries use
 // (madd-2008-s, add-2008-s, dbl-2008-s-1, mdbl-2008-s-1): SPK ec/xyzz_t.hpp:97-170 (add),
@@ -11,7 +11,7 @@
 //   Xyzz.zz, .zzz  : class M (normalized limbs, value < 2p);  infinity  <=>  zz == 0 (mod p)
 //   Affine.x, .y   : class M (canonical < p when produced by the base-conversion kernel)
 #pragma once
-#include "fp28.cuh"
+#include "fp28.hpp"
 
 namespace msm {
 
@@ -30,7 +30,7 @@ using Affine = AffineT<Fe>;
 using Xyzz = XyzzT<Fe>;
 
 // ---- coordinate-field policies -------------------------------------------------------------------------------
-// Every curve function below is written against this interface; contracts (limb / value bounds) are those of fp28.cuh:
+// Every curve function below is written against this interface; contracts (limb / value bounds) are those of fp28.hpp:
 //   mul/sqr inputs: limbs < 2^30, values <= 18p (what the formulas produce);  outputs: class M per component.
 //   mul2(r, a, b, c, d) = a*b + c*d with all limbs < 2^29; output limbs < 2^28 + 16, value < 4p per component.
 template <class F>

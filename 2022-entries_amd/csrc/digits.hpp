@@ -1,7 +1,7 @@
-// digits.cuh -- scalar windowing kernel (curve-independent apart from the scalar field constants).
+// digits.hpp -- scalar windowing kernel (curve-independent apart from the scalar field constants).
 // Reference behaviour: SPK msm/pippenger.cuh:116-123 (get_wval), CMB ProcessSignedDigits.cu:118-151 (signed digits).
 #pragma once
-#include "fp28.cuh"
+#include "fp28.hpp"
 
 namespace msm {
 

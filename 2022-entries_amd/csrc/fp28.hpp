@@ -1,4 +1,4 @@
-// fp28.cuh -- 384-bit prime-field arithmetic for gfx950, unsaturated radix-2^28 limbs.
+// fp28.hpp -- 384-bit prime-field arithmetic for gfx950, unsaturated radix-2^28 limbs.
 //
 // Why this shape (measured on MI355X, tools/ubench_valu.hip, profiles/r01_ubench_valu.txt):
 // v_mad_u64_u32 issues at the same ~4.3 cycles/wave as v_addc_co_u32, and gfx950 needs two wait
@@ -521,10 +521,41 @@ MSM_HD bool fe_is_zero_slow(const Fe& a) {
   return z == 0;
 }
 
-MSM_HD void fe_cmov(Fe& r, const Fe& a, bool take) {
-#pragma unroll
-  for (int i = 0; i < NL; i++) r.v[i] = take ? a.v[i] : r.v[i];
+// Lane mask of a per-lane condition, in an SGPR pair: the form v_cndmask_b32_e64 takes.
+// Why not leave the select to hipcc: it emits the VOP2 encoding (v_cndmask_b32_e32, condition implicit in VCC), which
+// gfx950 issues at 22.9 cycles per wave-instruction against 4.2 for the VOP3 encoding with the mask in VCC or any SGPR
+// pair (tools/ubench_valu.hip, profiles/r02_ubench_valu_w4.txt) -- 42 such selects were 7 % of a mixed addition.
+struct LaneMask {
+#if defined(__HIP_DEVICE_COMPILE__)
+  uint64_t m;
+#else
+  bool m;
+#endif
+};
+MSM_HD LaneMask lane_mask(bool take) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return LaneMask{__builtin_amdgcn_ballot_w64(take)};
+#else
+  return LaneMask{take};
+#endif
 }
+MSM_HD uint32_t sel_u32(uint32_t if_clear, uint32_t if_set, const LaneMask& k) {
+#if defined(__HIP_DEVICE_COMPILE__) && defined(MSM_CMOV_PLAIN)
+  return ((k.m >> __lane_id()) & 1) ? if_set : if_clear;   // A/B only: lets hipcc pick v_cndmask_b32_e32 again
+#elif defined(__HIP_DEVICE_COMPILE__)
+  uint32_t d;
+  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(d) : "v"(if_clear), "v"(if_set), "s"(k.m));
+  return d;
+#else
+  return k.m ? if_set : if_clear;
+#endif
+}
+
+MSM_HD void fe_cmov(Fe& r, const Fe& a, const LaneMask& k) {
+#pragma unroll
+  for (int i = 0; i < NL; i++) r.v[i] = sel_u32(r.v[i], a.v[i], k);
+}
+MSM_HD void fe_cmov(Fe& r, const Fe& a, bool take) { fe_cmov(r, a, lane_mask(take)); }
 
 // ---- ABI conversions (6 x u64 little-endian, Montgomery radix 2^384  <->  internal) ----------
 

@@ -6,7 +6,7 @@
 #include <stddef.h>
 #include <string.h>
 
-#include "curve.cuh"
+#include "curve.hpp"
 
 namespace msm {
 

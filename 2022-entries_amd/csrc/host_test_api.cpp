@@ -16,7 +16,7 @@ static void msm_check_fail(const char* file, int line, const char* cond) {
 #define MSM_CHECK_COL_END(col) MSM_CHECK(chk_col_ == (unsigned __int128)(col))
 
 #include "host_curve.hpp"
-#include "te.cuh"
+#include "te.hpp"
 
 using namespace msm;
 
@@ -201,7 +201,7 @@ static void t_normalize(const uint8_t* in, uint8_t* out) {
   xyzz_to_projective_abi<E>(out, a, md);
 }
 
-// ---- twisted-Edwards image of BLS12-377 G1 (te.cuh) ------------------------------------------------------------
+// ---- twisted-Edwards image of BLS12-377 G1 (te.hpp) ------------------------------------------------------------
 using TF = Bls12_377_Fq;
 
 // arkworks Affine image -> TE base record; false when the point has no image (or is flagged infinite).

@@ -1,7 +1,7 @@
-// kernels_377te.hip -- the walking kernels instantiated for the twisted-Edwards image of BLS12-377 G1 (te.cuh, laws.cuh),
+// kernels_377te.hip -- the walking kernels instantiated for the twisted-Edwards image of BLS12-377 G1 (te.hpp, laws.hpp),
 // and the base converter.  Its own translation unit so that it compiles in parallel with the per-curve units.
 #include "launch.hpp"
-#include "msm_kernels.cuh"
+#include "msm_kernels.hpp"
 
 namespace msm {
 
@@ -16,13 +16,9 @@ hipError_t LaunchTe::convert(const AffineDev* in, const uint8_t* inf, uint32_t n
   return hipGetLastError();
 }
 
-hipError_t LaunchTe::accumulate(const uint32_t* keys, const uint32_t* vals, uint32_t n_entries, uint32_t K, uint32_t sentinel,
+hipError_t LaunchTe::accumulate(const uint2* entries, const uint32_t* n_real, uint32_t K,
                                 const TeAffineDev* bases, SegOut out, uint32_t nlanes, uint32_t* flags, hipStream_t st) {
-  #ifdef TE_ONE_LANE_GATHER
-  hipLaunchKernelGGL((k_accumulate<G>), dim3(te_blocks(nlanes)), dim3(256), 0, st, keys, vals, n_entries, K, sentinel, bases, out, nlanes, flags);
-#else
-  hipLaunchKernelGGL((k_accumulate_coop<G>), dim3(te_blocks(nlanes)), dim3(256), 0, st, keys, vals, n_entries, K, sentinel, bases, out, nlanes, flags);
-#endif
+  hipLaunchKernelGGL((k_accumulate_coop<G>), dim3(te_blocks(nlanes)), dim3(256), 0, st, entries, n_real, K, bases, out, nlanes, flags);
   return hipGetLastError();
 }
 

@@ -1,12 +1,13 @@
-// launch.hpp -- host-callable launchers of the per-curve kernels.  Declared here, defined in launch_impl.cuh and
+// launch.hpp -- host-callable launchers of the per-curve kernels.  Declared here, defined in launch_impl.hpp and
 // explicitly instantiated once per curve in kernels_<curve>.hip, so the three curve instantiations (each minutes of
 // hipcc time: every field multiply is fully unrolled) compile in parallel and the engine TU stays small.
 #pragma once
 #include <hip/hip_runtime.h>
 
 #include "host_curve.hpp"
-#include "msm_types.cuh"
-#include "te.cuh"
+#include "msm_types.hpp"
+#include "partition_plan.hpp"
+#include "te.hpp"
 
 namespace msm {
 
@@ -15,7 +16,7 @@ struct Launch {
   using El = typename E::T;
   static hipError_t convert_bases(const uint8_t* in, size_t stride, uint32_t n, bool serialized, AffineDevT<El>* out, uint8_t* inf,
                                   hipStream_t st);
-  static hipError_t accumulate(const uint32_t* keys, const uint32_t* vals, uint32_t n_entries, uint32_t K, uint32_t sentinel,
+  static hipError_t accumulate(const uint2* entries, const uint32_t* n_real, uint32_t K,
                                const AffineDevT<El>* bases, SegOutT<El> out, uint32_t nlanes, hipStream_t st);
   static hipError_t segreduce(const XyzzDevT<El>* in_slots, const uint32_t* in_keys, uint32_t n_in, uint32_t K, SegOutT<El> out,
                               uint32_t nlanes, hipStream_t st);
@@ -31,12 +32,19 @@ struct Launch {
 struct LaunchTe {
   static hipError_t convert(const AffineDev* in, const uint8_t* inf, uint32_t n, uint32_t J, Fe* prefix, TeAffineDev* out, uint32_t* flags,
                             hipStream_t st);
-  static hipError_t accumulate(const uint32_t* keys, const uint32_t* vals, uint32_t n_entries, uint32_t K, uint32_t sentinel,
+  static hipError_t accumulate(const uint2* entries, const uint32_t* n_real, uint32_t K,
                                const TeAffineDev* bases, SegOut out, uint32_t nlanes, uint32_t* flags, hipStream_t st);
   static hipError_t segreduce(const XyzzDev* in_slots, const uint32_t* in_keys, uint32_t n_in, uint32_t K, SegOut out, uint32_t nlanes,
                               uint32_t* flags, hipStream_t st);
   static hipError_t bucket_reduce(bool first, const XyzzDev* in_a, const XyzzDev* in_x, uint32_t n_per_win, uint32_t logL, uint32_t chunks,
                                   uint32_t windows, XyzzDev* out_a, XyzzDev* out_x, uint32_t* flags, hipStream_t st);
+};
+
+// Bucket grouping (partition.hip): digits + MSD partition of the (key, value) entries.  scalar_field: 0 = BLS12-377 Fr, 1 = BLS12-381 Fr
+// (only the Montgomery conversion depends on it).  Returns the index of the entry buffer that holds the sorted entries.
+struct PartLaunch {
+  static int run(int scalar_field, bool montgomery, const uint32_t* d_scalars, const uint8_t* d_inf, const PartPlan& p, const PartBuffers& b,
+                 hipStream_t st, hipEvent_t mid, hipError_t& err);
 };
 
 extern template struct Launch<Bls12_377_G1::E>;

@@ -1,7 +1,7 @@
-// launch_impl.cuh -- definitions of Launch<E>; include only from kernels_<curve>.hip.
+// launch_impl.hpp -- definitions of Launch<E>; include only from kernels_<curve>.hip.
 #pragma once
 #include "launch.hpp"
-#include "msm_kernels.cuh"
+#include "msm_kernels.hpp"
 
 namespace msm {
 
@@ -18,15 +18,15 @@ hipError_t Launch<E>::convert_bases(const uint8_t* in, size_t stride, uint32_t n
 }
 
 template <class E>
-hipError_t Launch<E>::accumulate(const uint32_t* keys, const uint32_t* vals, uint32_t n_entries, uint32_t K, uint32_t sentinel,
+hipError_t Launch<E>::accumulate(const uint2* entries, const uint32_t* n_real, uint32_t K,
                                  const AffineDevT<El>* bases, SegOutT<El> out, uint32_t nlanes, hipStream_t st) {
   // G1 (128-B records): quad-cooperative gathers (-2.7 % on BLS12-381, tools/ab_bench.sh); G2 keeps one lane per record
   if constexpr (sizeof(AffineDevT<El>) == 128) {
-    hipLaunchKernelGGL((k_accumulate_coop<SwLaw<E>>), dim3(launch_blocks(nlanes)), dim3(256), 0, st, keys, vals, n_entries, K, sentinel, bases, out,
+    hipLaunchKernelGGL((k_accumulate_coop<SwLaw<E>>), dim3(launch_blocks(nlanes)), dim3(256), 0, st, entries, n_real, K, bases, out,
                        nlanes, (uint32_t*)nullptr);
     return hipGetLastError();
   }
-  hipLaunchKernelGGL((k_accumulate<SwLaw<E>>), dim3(launch_blocks(nlanes)), dim3(256), 0, st, keys, vals, n_entries, K, sentinel, bases, out, nlanes,
+  hipLaunchKernelGGL((k_accumulate<SwLaw<E>>), dim3(launch_blocks(nlanes)), dim3(256), 0, st, entries, n_real, K, bases, out, nlanes,
                      (uint32_t*)nullptr);
   return hipGetLastError();
 }

@@ -1,16 +1,16 @@
-// laws.cuh -- the group-law policies the walking kernels (k_accumulate, k_segreduce, k_bucket_reduce) are written against.
+// laws.hpp -- the group-law policies the walking kernels (k_accumulate, k_segreduce, k_bucket_reduce) are written against.
 //
-//   SwLaw<E>  short Weierstrass, XYZZ accumulators, affine (x, y) base records            -- every curve (curve.cuh)
-//   TeLaw<F>  twisted-Edwards image of BLS12-377 G1, extended accumulators, (X, Y, 2dXY)   -- the fast path (te.cuh)
+//   SwLaw<E>  short Weierstrass, XYZZ accumulators, affine (x, y) base records            -- every curve (curve.hpp)
+//   TeLaw<F>  twisted-Edwards image of BLS12-377 G1, extended accumulators, (X, Y, 2dXY)   -- the fast path (te.hpp)
 //
 // Interface:  Point (always XyzzT<T>: the 4-coordinate accumulator, so slots/buckets/fragments share one layout),
 //   Base/BaseDev (what a lane gathers), set_identity, begin_run(acc) at every change of key, madd(acc, base, negate, fresh), add(acc, b) where b may be an
 //   all-zero "empty" record (a bucket nobody wrote), mul_pow2(acc, k), and failed(acc): true when the law could not
 //   compute the last result (TeLaw only: a vanishing denominator off the odd-order subgroup) -- kernels raise a flag then.
 #pragma once
-#include "curve.cuh"
-#include "msm_types.cuh"
-#include "te.cuh"
+#include "curve.hpp"
+#include "msm_types.hpp"
+#include "te.hpp"
 
 namespace msm {
 

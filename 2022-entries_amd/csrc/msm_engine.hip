@@ -3,7 +3,7 @@
 // Role in the reference: the L1 "host orchestration" + L2 "C-ABI" layers of SURVEY.md section 1
 // (SPK msm/pippenger.cuh:247-662 pippenger_t, CMB MSM.cu:149-532 MSMContext, ML msm.cu:97-468).
 // One context = one device, one stream; bases are converted once and stay resident in HBM; a run is
-//   digits -> radix sort by (window, bucket) -> accumulate -> fragment merge -> bucket reduce -> host fold.
+//   digits + bucket grouping (partition.hpp) -> accumulate -> fragment merge -> bucket reduce -> host fold.
 // Everything is enqueued on one stream with no host round-trip until the W window sums (W * 224 B) come back.
 #include <hip/hip_runtime.h>
 
@@ -14,9 +14,12 @@
 #include <cstring>
 #include <string.h>
 
-#include <rocprim/rocprim.hpp>
+#include <dlfcn.h>
+
+#include <chrono>
 #include <functional>
 #include <stdexcept>
+#include <thread>
 #include <type_traits>
 #include <string>
 #include <vector>
@@ -24,7 +27,6 @@
 #include "../../include/mi355_msm.h"
 #include "host_curve.hpp"
 #include "launch.hpp"
-#include "digits.cuh"
 
 namespace {
 
@@ -77,13 +79,23 @@ RustError guarded(Fn&& fn) {
   }
 }
 
+// Test hook ("inject_alloc_failures" option): the next N work-buffer reservations of this thread's chunks fail as if HBM were exhausted.
+thread_local long g_inject_alloc_failures = 0;
+
 struct DevBuf {
   void* p = nullptr;
   size_t bytes = 0;
   void reserve(size_t need) {
     if (need <= bytes) return;
     release();
-    HIP_OK(hipMalloc(&p, need));
+    hipError_t e = hipMalloc(&p, need);
+    if (e != hipSuccess) {
+      p = nullptr;
+      (void)hipGetLastError();   // clear the sticky per-thread error so that a retry with smaller buffers starts clean
+      char buf[256];
+      snprintf(buf, sizeof buf, "hipMalloc of %zu MiB failed: %s", need >> 20, hipGetErrorString(e));
+      throw HipFailure((int)e, buf);
+    }
     bytes = need;
   }
   void release() {
@@ -128,6 +140,8 @@ struct Plan {
 
 }  // namespace
 
+struct RcclState;   // the dlopen'ed RCCL entry points and one communicator per shard (sharded contexts only)
+
 struct mi355_msm_ctx {
   int curve = 0;
   int device = 0;
@@ -136,7 +150,8 @@ struct mi355_msm_ctx {
   hipEvent_t copy_ev[3] = {};   // batch parity 0/1 resident, first piece of batch 0 resident
   size_t nbases = 0;
   DevBuf bases, inf;
-  DevBuf scalars, keys[2], vals[2], sort_tmp, buckets, slots[2], slot_keys[2], red_a[2], red_x[2];
+  DevBuf scalars, entries[2], buckets, slots[2], slot_keys[2], red_a[2], red_x[2];
+  DevBuf part_matrix, part_partial, part_segs[2], part_subjobs, part_counts, part_totals;   // bucket grouping scratch (partition_plan.hpp)
   void* pinned = nullptr;  // window sums land here
   size_t pinned_bytes = 0;
   hipEvent_t ev[8] = {};
@@ -144,12 +159,25 @@ struct mi355_msm_ctx {
   long opt_precompute = 0;
   long opt_reduce_log_chunk = 0;
   long opt_twisted_edwards = 1;   // BLS12-377 G1 only: accumulate on the twisted-Edwards image when every base has one
-  // twisted-Edwards fast path (te.cuh): records for every table level; te_active is decided per base set
+  // twisted-Edwards fast path (te.hpp): records for every table level; te_active is decided per base set
   DevBuf te_bases, flags;         // flags: u32[2] on the device, [0] bases without an image, [1] an addition failed
   uint32_t* h_flags = nullptr;    // pinned copy
   bool te_active = false;
   bool sw_level0_only = false;    // the short-Weierstrass tables were dropped after conversion (only level 0 is kept)
   uint64_t te_fallbacks = 0;      // runs repeated on the XYZZ path because an addition reported a vanishing denominator
+  uint32_t te_fallback_streak = 0;   // consecutive chunks that fell back; two in a row demote the context to XYZZ for good
+  uint64_t te_demotions = 0;
+  uint64_t oom_backoffs = 0;      // chunks restarted with half the chunk size after a device allocation failed
+  size_t chunk_cap = 0;           // 0 = none; otherwise the largest chunk the work buffers were found to fit (see fit_chunk)
+  size_t fitted_chunk = 0;        // largest chunk that has run with the current buffers and options (skips the fit query)
+  bool fitted_tables = false;
+  long opt_mem_limit = 0;         // test hook: pretend the device has at most this many free bytes when sizing chunks
+  // sharded context (mi355_msm_create_sharded): this object then owns no device state itself, only the per-device children
+  std::vector<mi355_msm_ctx*> shards;
+  std::vector<size_t> shard_lo;   // bases [shard_lo[g], shard_lo[g+1]) live on shard g
+  long opt_combine = 0;           // 0 auto (RCCL all-gather when available and the devices are distinct), 1 host fold only, 2 require RCCL
+  RcclState* rccl = nullptr;
+  uint64_t rccl_exchanges = 0;
   // precomputed tables (row f1): level w at bases[w * nbases ...] holds 2^(pre_c * w) * P; 0 = none
   uint32_t pre_c = 0, pre_windows = 0;
   bool bases_serialized = false;  // set only for the duration of mi355_msm_set_bases_serialized
@@ -192,6 +220,52 @@ struct mi355_msm_ctx {
 namespace {
 
 void ensure_device(mi355_msm_ctx* ctx) { HIP_OK(hipSetDevice(ctx->device)); }
+
+// Device bytes of the per-run work buffers of one chunk (keys/vals x2, buckets, slots x2, reduce x4); `el` = 2 for Fq2 points.
+uint64_t work_bytes(const Plan& p, uint64_t el) {
+  const PartPlan pp = part_plan((uint32_t)(p.entries / p.windows), p.c, p.windows, p.bucket_windows == 1 && p.windows > 1, 0, 0);
+  const PartScratchSizes ps = part_scratch_sizes(pp);
+  return p.entries * 16 + ps.matrix + ps.partial + ps.segs_a + ps.segs_b + ps.subjob_first + ps.counts + ps.totals +
+         (uint64_t)p.bucket_windows * p.half * 224 * el + 2 * (2ull * p.nlanes) * (224 * el + 4) + 4ull * p.bucket_windows * p.T0 * 224 * el;
+}
+
+DevBuf* const* work_buffers(mi355_msm_ctx* ctx, size_t& count) {
+  static thread_local DevBuf* bufs[24];
+  DevBuf* list[] = {&ctx->entries[0], &ctx->entries[1], &ctx->part_matrix, &ctx->part_partial, &ctx->part_segs[0], &ctx->part_segs[1],
+                    &ctx->part_subjobs, &ctx->part_counts, &ctx->part_totals, &ctx->buckets, &ctx->slots[0], &ctx->slots[1],
+                    &ctx->slot_keys[0], &ctx->slot_keys[1], &ctx->red_a[0], &ctx->red_a[1], &ctx->red_x[0], &ctx->red_x[1]};
+  count = sizeof list / sizeof list[0];
+  for (size_t i = 0; i < count; i++) bufs[i] = list[i];
+  return bufs;
+}
+
+// The largest chunk (<= want) whose work buffers fit the device memory that is free now or already held by this context
+// for the purpose -- the reference plans its allocations before it runs, too (ML msm.cu:453-466).  Halves until it fits.
+size_t fit_chunk(mi355_msm_ctx* ctx, size_t want, bool use_tables) {
+  size_t free_b = 0, total_b = 0;
+  HIP_OK(hipMemGetInfo(&free_b, &total_b));
+  size_t held = 0, nb = 0;
+  DevBuf* const* wb = work_buffers(ctx, nb);
+  for (size_t i = 0; i < nb; i++) held += wb[i]->bytes;
+  uint64_t avail = (uint64_t)free_b + held;
+  if (ctx->opt_mem_limit > 0 && (uint64_t)ctx->opt_mem_limit < avail) avail = (uint64_t)ctx->opt_mem_limit;
+  const uint64_t el = ctx->curve == MI355_BLS12_377_G2 ? 2 : 1;
+  size_t cn = want;
+  while (cn > 1024) {
+    const Plan p = ctx->plan(cn, use_tables);
+    // 3 % head-room for the sort's temporary storage and allocator granularity
+    if (p.entries < (1ull << 32) && work_bytes(p, el) + (work_bytes(p, el) >> 5) <= avail) break;
+    cn = (cn + 1) / 2;
+  }
+  return cn;
+}
+
+void release_work_buffers(mi355_msm_ctx* ctx) {
+  ctx->fitted_chunk = 0;
+  size_t nb = 0;
+  DevBuf* const* wb = work_buffers(ctx, nb);
+  for (size_t i = 0; i < nb; i++) wb[i]->release();
+}
 
 // Run `fn.template operator()<Curve>()` for the curve id.
 template <class Fn>
@@ -258,7 +332,7 @@ void build_tables(mi355_msm_ctx* ctx, const uint8_t* d_raw, size_t n, size_t str
   ctx->pre_windows = windows;
 }
 
-// BLS12-377 G1: twisted-Edwards records for every table level (te.cuh).  The base set takes the fast path only if every
+// BLS12-377 G1: twisted-Edwards records for every table level (te.hpp).  The base set takes the fast path only if every
 // (non-infinite) entry has an image; otherwise, or when the records do not fit, the context stays on XYZZ.
 void build_te(mi355_msm_ctx* ctx, size_t n, hipStream_t st) {
   const size_t levels = ctx->pre_c ? ctx->pre_windows : 1;
@@ -309,6 +383,7 @@ void set_bases_device(mi355_msm_ctx* ctx, const void* d_affine, size_t n, size_t
   ctx->pre_c = ctx->pre_windows = 0;
   ctx->nbases = 0;
   ctx->te_active = false;
+  ctx->te_fallback_streak = 0;
   ctx->sw_level0_only = false;
   if (n) {
     if (ctx->opt_precompute)
@@ -357,10 +432,21 @@ bool run_chunk_impl(mi355_msm_ctx* ctx, const uint32_t* d_scalars, size_t base0,
   const Plan p = ctx->plan(n, use_tables);
   if (p.entries >= (1ull << 32)) bad_arg("chunk of %zu pairs needs %llu sort entries (>= 2^32)", n, (unsigned long long)p.entries);
   const size_t NE = p.entries;
-  for (int i = 0; i < 2; i++) {
-    ctx->keys[i].reserve(NE * 4);
-    ctx->vals[i].reserve(NE * 4);
+  if (g_inject_alloc_failures > 0) {
+    g_inject_alloc_failures--;
+    throw HipFailure((int)hipErrorOutOfMemory, "work-buffer reservation failed: out of memory (injected by the inject_alloc_failures test hook)");
   }
+  for (int i = 0; i < 2; i++) ctx->entries[i].reserve(NE * 8 + 64);
+  const uint32_t table_stride = use_tables ? (uint32_t)ctx->nbases : 0u;
+  const PartPlan gp = part_plan((uint32_t)n, p.c, p.windows, use_tables, (uint32_t)base0, table_stride);
+  const PartScratchSizes gs = part_scratch_sizes(gp);
+  ctx->part_matrix.reserve(gs.matrix);
+  ctx->part_partial.reserve(gs.partial);
+  ctx->part_segs[0].reserve(gs.segs_a);
+  ctx->part_segs[1].reserve(gs.segs_b);
+  ctx->part_subjobs.reserve(gs.subjob_first);
+  ctx->part_counts.reserve(gs.counts);
+  ctx->part_totals.reserve(gs.totals);
   const size_t nbuckets = (size_t)p.bucket_windows * p.half;
   ctx->buckets.reserve(nbuckets * sizeof(XyzzDev));
   const size_t nslots0 = 2 * (size_t)p.nlanes;
@@ -379,37 +465,36 @@ bool run_chunk_impl(mi355_msm_ctx* ctx, const uint32_t* d_scalars, size_t base0,
     HIP_OK(hipHostMalloc(&ctx->pinned, ctx->pinned_bytes, hipHostMallocDefault));
   }
 
-  rocprim::double_buffer<uint32_t> kbuf(ctx->keys[0].as<uint32_t>(), ctx->keys[1].as<uint32_t>());
-  rocprim::double_buffer<uint32_t> vbuf(ctx->vals[0].as<uint32_t>(), ctx->vals[1].as<uint32_t>());
-  size_t tmp_bytes = 0;
-  HIP_OK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, kbuf, vbuf, NE, 0, p.keybits, st));
-  ctx->sort_tmp.reserve(tmp_bytes ? tmp_bytes : 16);
-
   const AffineDev* bases = ctx->bases.as<AffineDev>();
   const uint8_t* inf = ctx->inf.as<uint8_t>();
-  const uint32_t table_stride = use_tables ? (uint32_t)ctx->nbases : 0u;
   uint32_t* flags = ctx->flags.as<uint32_t>();
 
+  // digits + bucket grouping: (value, key) entries sorted by key in entries[sorted]; the count of real entries stays on the device
   HIP_OK(hipEventRecord(ctx->ev[0], st));
-  using FR = typename C::FR;
-  if (ctx->opt_scalars_montgomery)
-    hipLaunchKernelGGL((k_digits<FR, true>), dim3(ceil_div(n, 256)), dim3(256), 0, st, d_scalars, inf, (uint32_t)n, p.c,
-                       p.windows, (uint32_t)base0, table_stride, kbuf.current(), vbuf.current());
-  else
-    hipLaunchKernelGGL((k_digits<FR, false>), dim3(ceil_div(n, 256)), dim3(256), 0, st, d_scalars, inf, (uint32_t)n, p.c,
-                       p.windows, (uint32_t)base0, table_stride, kbuf.current(), vbuf.current());
-  HIP_OK(hipGetLastError());
-  HIP_OK(hipEventRecord(ctx->ev[1], st));
-  HIP_OK(rocprim::radix_sort_pairs(ctx->sort_tmp.p, tmp_bytes, kbuf, vbuf, NE, 0, p.keybits, st));
+  PartBuffers gb{};
+  gb.entries[0] = ctx->entries[0].as<uint2>();
+  gb.entries[1] = ctx->entries[1].as<uint2>();
+  gb.matrix = ctx->part_matrix.as<uint32_t>();
+  gb.partial = ctx->part_partial.as<uint32_t>();
+  gb.segs[0] = ctx->part_segs[0].as<PartSeg>();
+  gb.segs[1] = ctx->part_segs[1].as<PartSeg>();
+  gb.subjob_first = ctx->part_subjobs.as<uint32_t>();
+  gb.counts = ctx->part_counts.as<uint32_t>();
+  gb.totals = ctx->part_totals.as<uint32_t>();
+  hipError_t gerr = hipSuccess;
+  const int sorted = PartLaunch::run(ctx->curve == MI355_BLS12_381_G1 ? 1 : 0, ctx->opt_scalars_montgomery != 0, d_scalars, inf, gp, gb, st,
+                                     ctx->ev[1], gerr);
+  HIP_OK(gerr);
+  const uint2* entries = gb.entries[sorted];
+  const uint32_t* n_real = gb.totals;
   HIP_OK(hipMemsetAsync(ctx->buckets.p, 0, nbuckets * sizeof(XyzzDev), st));
   HIP_OK(hipEventRecord(ctx->ev[2], st));
 
   SegOut so{ctx->buckets.as<XyzzDev>(), ctx->slots[0].as<XyzzDev>(), ctx->slot_keys[0].as<uint32_t>()};
   if constexpr (TE)
-    HIP_OK(LaunchTe::accumulate(kbuf.current(), vbuf.current(), (uint32_t)p.entries, p.K, p.sentinel, ctx->te_bases.as<TeAffineDev>(), so,
-                                p.nlanes, flags, st));
+    HIP_OK(LaunchTe::accumulate(entries, n_real, p.K, ctx->te_bases.as<TeAffineDev>(), so, p.nlanes, flags, st));
   else
-    HIP_OK(Launch<E>::accumulate(kbuf.current(), vbuf.current(), (uint32_t)p.entries, p.K, p.sentinel, bases, so, p.nlanes, st));
+    HIP_OK(Launch<E>::accumulate(entries, n_real, p.K, bases, so, p.nlanes, st));
   HIP_OK(hipEventRecord(ctx->ev[3], st));
 
   // merge the run fragments that crossed lane boundaries
@@ -496,10 +581,20 @@ void run_chunk(mi355_msm_ctx* ctx, const uint32_t* d_scalars, size_t base0, size
                XyzzT<typename C::E::T>& out, const std::function<void()>* while_gpu_busy = nullptr) {
   if constexpr (std::is_same_v<C, Bls12_377_G1>) {
     if (ctx->te_active) {
-      if (run_chunk_impl<C, true>(ctx, d_scalars, base0, n, st, out, while_gpu_busy)) return;
+      if (run_chunk_impl<C, true>(ctx, d_scalars, base0, n, st, out, while_gpu_busy)) {
+        ctx->te_fallback_streak = 0;
+        return;
+      }
       ctx->te_fallbacks++;
       // (the hook -- the next batch's H2D copy -- has run already)
       run_chunk_impl<C, false>(ctx, d_scalars, base0, n, st, out, nullptr);
+      // A base set that trips the incomplete law twice in a row (points outside the prime-order subgroup) would pay for
+      // both paths on every call: demote the context to XYZZ for good and give the twisted-Edwards records back.
+      if (++ctx->te_fallback_streak >= 2) {
+        ctx->te_active = false;
+        ctx->te_demotions++;
+        ctx->te_bases.release();
+      }
       return;
     }
   }
@@ -510,15 +605,18 @@ void run_chunk(mi355_msm_ctx* ctx, const uint32_t* d_scalars, size_t base0, size
 // (the reference's double-buffered batches, P1A 6block/cuda/pippenger_inf.cu:110-160; CMB MSM.cu:419-505), and the FIRST
 // batch -- whose copy nothing can hide -- is handed over in two pieces, 1/4 then 3/4, so that the first quarter is already
 // accumulating while the rest crosses PCIe (the reference's quarter-split first copy, CMB MSM.cu:419-434).
+// `host_batch_bytes` is the distance between two batches in the CALLER's buffer: a shard of a sharded context reads its
+// slice out of batches that are npoints_total scalars apart.
 struct HostBatches {
   const uint8_t* host;
   uint8_t* dev;
-  size_t batch_bytes;
+  size_t batch_bytes;        // bytes of one batch on the device (n * 32)
+  size_t host_batch_bytes;   // bytes between batches in the host buffer
   hipStream_t copy_stream;
   hipEvent_t ready[2];   // whole batch b resident: ready[b & 1]
   hipEvent_t head;       // first piece of batch 0 resident
   void copy_pairs(size_t b, size_t first, size_t count, hipEvent_t ev) const {
-    HIP_OK(hipMemcpyAsync(dev + b * batch_bytes + first * 32, host + b * batch_bytes + first * 32, count * 32, hipMemcpyHostToDevice,
+    HIP_OK(hipMemcpyAsync(dev + b * batch_bytes + first * 32, host + b * host_batch_bytes + first * 32, count * 32, hipMemcpyHostToDevice,
                           copy_stream));
     HIP_OK(hipEventRecord(ev, copy_stream));
   }
@@ -532,13 +630,16 @@ inline size_t first_piece_pairs(size_t n, size_t max_chunk) {
   return std::min(n / 4, max_chunk);
 }
 
+// `dev_batch_pairs`: distance (in scalars) between two batches in the device buffer (n, or the total of a sharded run when a
+// shard reads its slice in place).
 template <class C>
-void run_device_t(mi355_msm_ctx* ctx, uint8_t* out, const uint32_t* d_scalars, size_t n, size_t batches, hipStream_t st,
-                  const HostBatches* hb) {
+void run_device_t(mi355_msm_ctx* ctx, uint8_t* out, const uint32_t* d_scalars, size_t n, size_t batches, size_t dev_batch_pairs,
+                  hipStream_t st, const HostBatches* hb) {
   using E = typename C::E;
   using Xyzz = XyzzT<typename E::T>;
   typename E::Md md;
-  const size_t max_chunk = ctx->opt_max_chunk ? (size_t)ctx->opt_max_chunk : ((size_t)1 << 26);
+  size_t max_chunk = ctx->opt_max_chunk ? (size_t)ctx->opt_max_chunk : ((size_t)1 << 26);
+  if (ctx->chunk_cap) max_chunk = std::min(max_chunk, ctx->chunk_cap);
   const size_t out_bytes = 3 * 4 * E::WORDS;
   const size_t head = (hb && batches) ? first_piece_pairs(n, max_chunk) : 0;
   if (hb && batches && n) {
@@ -552,32 +653,63 @@ void run_device_t(mi355_msm_ctx* ctx, uint8_t* out, const uint32_t* d_scalars, s
     xyzz_set_inf<E>(total);
     const bool split = head && b == 0;
     if (hb && n) HIP_OK(hipStreamWaitEvent(st, split ? hb->head : hb->ready[b & 1], 0));
-    const std::function<void()> rest_of_first = [&] { hb->copy_pairs(0, head, n - head, hb->ready[0]); };
+    bool rest_issued = !split, rest_awaited = !split, prefetched = false;
+    const std::function<void()> rest_of_first = [&] {
+      hb->copy_pairs(0, head, n - head, hb->ready[0]);
+      rest_issued = true;
+    };
     const std::function<void()> prefetch = [&] {
       if (hb && b + 1 < batches) hb->copy(b + 1);
+      prefetched = true;
     };
     for (size_t off = 0; off < n;) {
-      const size_t cn = (split && off == 0) ? head : std::min(max_chunk, n - off);
+      // plan the chunk against the memory that is there (ML msm.cu:453-466 plans first, too) ...
+      const bool tables_now = ctx->pre_c && (ctx->te_active || !ctx->sw_level0_only);
+      size_t cn = std::min(max_chunk, n - off);
+      if (split && off < head) cn = std::min(cn, head - off);
+      if (cn > ctx->fitted_chunk || tables_now != ctx->fitted_tables) cn = fit_chunk(ctx, cn, tables_now);
       const bool last = off + cn >= n;
+      if (split && !rest_awaited && off + cn > head) {
+        if (!rest_issued) rest_of_first();
+        HIP_OK(hipStreamWaitEvent(st, hb->ready[0], 0));
+        rest_awaited = true;
+      }
       Xyzz part;
-      if (split && off == head) HIP_OK(hipStreamWaitEvent(st, hb->ready[0], 0));
-      run_chunk<C>(ctx, d_scalars + (b * n + off) * 8, off, cn, st, part,
-                   (split && off == 0) ? &rest_of_first : (last ? &prefetch : nullptr));
+      const std::function<void()>* hook = (!rest_issued) ? &rest_of_first : ((last && !prefetched) ? &prefetch : nullptr);
+      try {
+        run_chunk<C>(ctx, d_scalars + (b * dev_batch_pairs + off) * 8, off, cn, st, part, hook);
+      } catch (const HipFailure& e) {
+        // ... and if an allocation fails all the same (fragmentation, another tenant), give the work buffers back and go on
+        // with half the chunk; results do not depend on the chunking
+        if (e.code != (int)hipErrorOutOfMemory || cn <= 1024) throw;
+        (void)hipStreamSynchronize(st);
+        release_work_buffers(ctx);
+        max_chunk = ctx->chunk_cap = (cn + 1) / 2;
+        ctx->oom_backoffs++;
+        continue;
+      }
+      if (cn > ctx->fitted_chunk || tables_now != ctx->fitted_tables) {
+        ctx->fitted_chunk = cn;
+        ctx->fitted_tables = tables_now;
+      }
       xyzz_add<E>(total, part, md);
       off += cn;
     }
+    if (!prefetched) prefetch();   // n == 0
+    const auto t0 = std::chrono::steady_clock::now();
     xyzz_to_projective_abi<E>(out + b * out_bytes, total, md);
+    ctx->last_ms[MI355_T_HOST_FOLD] += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
   }
 }
 
-void run_device(mi355_msm_ctx* ctx, void* out, const void* d_scalars, size_t n, size_t batches, hipStream_t st,
+void run_device(mi355_msm_ctx* ctx, void* out, const void* d_scalars, size_t n, size_t batches, size_t dev_batch_pairs, hipStream_t st,
                 const HostBatches* hb = nullptr) {
   ensure_device(ctx);
   if (n > ctx->nbases) bad_arg("npoints %zu exceeds the %zu uploaded bases", n, ctx->nbases);
   if (!out) bad_arg("null output pointer");
   memset(ctx->last_ms, 0, sizeof ctx->last_ms);
   memset(ctx->last_info, 0, sizeof ctx->last_info);
-  with_curve(ctx->curve, [&]<class C>() { run_device_t<C>(ctx, (uint8_t*)out, (const uint32_t*)d_scalars, n, batches, st, hb); });
+  with_curve(ctx->curve, [&]<class C>() { run_device_t<C>(ctx, (uint8_t*)out, (const uint32_t*)d_scalars, n, batches, dev_batch_pairs, st, hb); });
 }
 
 template <class C>
@@ -594,7 +726,51 @@ void fold_t(uint8_t* out, const uint8_t* in, size_t count) {
   xyzz_to_projective_abi<E>(out, total, md);
 }
 
+// ---- single-device entry bodies (shared by the C ABI below and by the shards of a sharded context) -------------------
+
+void set_bases_host(mi355_msm_ctx* ctx, const void* affine, size_t npoints, size_t stride, bool serialized) {
+  ensure_device(ctx);
+  DevBuf raw;
+  ctx->bases_serialized = serialized;
+  try {
+    if (npoints) {
+      raw.reserve(npoints * stride);
+      HIP_OK(hipMemcpy(raw.p, affine, npoints * stride, hipMemcpyHostToDevice));
+    }
+    set_bases_device(ctx, raw.p, npoints, stride);
+  } catch (...) {
+    ctx->bases_serialized = false;
+    raw.release();
+    throw;
+  }
+  ctx->bases_serialized = false;
+  raw.release();
+}
+
+// Scalars in host memory: `batches` vectors of n scalars, `host_batch_pairs` scalars apart in the caller's buffer.
+void run_host(mi355_msm_ctx* ctx, void* out, const void* scalars, size_t n, size_t batches, size_t host_batch_pairs) {
+  ensure_device(ctx);
+  const size_t bytes = n * batches * 32;
+  ctx->scalars.reserve(bytes ? bytes : 32);
+  if (!ctx->copy_stream) {
+    HIP_OK(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    for (auto& ev : ctx->copy_ev) HIP_OK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  }
+  HostBatches hb{(const uint8_t*)scalars, ctx->scalars.as<uint8_t>(), n * 32, host_batch_pairs * 32, ctx->copy_stream,
+                 {ctx->copy_ev[0], ctx->copy_ev[1]}, ctx->copy_ev[2]};
+  try {
+    run_device(ctx, out, ctx->scalars.p, n, batches, n, ctx->own_stream, &hb);
+  } catch (...) {
+    // copies out of the caller's buffer may still be in flight: the caller is free to release it once we return
+    (void)hipStreamSynchronize(ctx->copy_stream);
+    (void)hipStreamSynchronize(ctx->own_stream);
+    throw;
+  }
+}
+
 }  // namespace
+
+#include "msm_sharded.hpp"
 
 extern "C" {
 
@@ -629,12 +805,16 @@ RustError mi355_msm_create(mi355_msm_ctx** out, int curve, int device) {
 RustError mi355_msm_destroy(mi355_msm_ctx* ctx) {
   return guarded([&] {
     if (!ctx) return;
+    if (!ctx->shards.empty()) {
+      sharded_destroy(ctx);
+      delete ctx;
+      return;
+    }
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->own_stream);
-    DevBuf* bufs[] = {&ctx->bases, &ctx->inf, &ctx->scalars, &ctx->keys[0], &ctx->keys[1], &ctx->vals[0], &ctx->vals[1],
-                      &ctx->sort_tmp, &ctx->buckets, &ctx->slots[0], &ctx->slots[1], &ctx->slot_keys[0], &ctx->slot_keys[1],
-                      &ctx->red_a[0], &ctx->red_a[1], &ctx->red_x[0], &ctx->red_x[1], &ctx->te_bases, &ctx->flags};
+    DevBuf* bufs[] = {&ctx->bases, &ctx->inf, &ctx->scalars, &ctx->te_bases, &ctx->flags};
     for (DevBuf* b : bufs) b->release();
+    release_work_buffers(ctx);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->h_flags) (void)hipHostFree(ctx->h_flags);
     for (auto& ev : ctx->ev)
@@ -647,23 +827,37 @@ RustError mi355_msm_destroy(mi355_msm_ctx* ctx) {
   });
 }
 
+RustError mi355_msm_create_sharded(mi355_msm_ctx** out, int curve, const int* devices, int ndevices) {
+  return guarded([&] {
+    if (!out) bad_arg("null context out-pointer");
+    *out = nullptr;
+    if (!known_curve(curve)) bad_arg("unknown curve id %d", curve);
+    if (!devices || ndevices < 1 || ndevices > 64) bad_arg("sharded context needs 1..64 devices");
+    *out = sharded_create(curve, devices, ndevices);
+  });
+}
+
+RustError mi355_msm_create_env(mi355_msm_ctx** out, int curve) {
+  // MI355_MSM_DEVICES = "0,1,2,3" | "all" | unset: a harness that never heard of more than one GPU picks them up here
+  const char* env = getenv("MI355_MSM_DEVICES");
+  if (!env || !*env) return mi355_msm_create(out, curve, -1);
+  std::vector<int> devs;
+  try {
+    devs = parse_device_list(env);
+  } catch (const std::exception& e) {
+    if (out) *out = nullptr;
+    return fail(-1, e.what());
+  }
+  if (devs.size() == 1) return mi355_msm_create(out, curve, devs[0]);
+  return mi355_msm_create_sharded(out, curve, devs.data(), (int)devs.size());
+}
+
 RustError mi355_msm_set_bases(mi355_msm_ctx* ctx, const void* affine, size_t npoints, size_t stride) {
   return guarded([&] {
     if (!ctx) bad_arg("null context");
     if (npoints && !affine) bad_arg("null bases pointer");
-    ensure_device(ctx);
-    DevBuf raw;
-    try {
-      if (npoints) {
-        raw.reserve(npoints * stride);
-        HIP_OK(hipMemcpy(raw.p, affine, npoints * stride, hipMemcpyHostToDevice));
-      }
-      set_bases_device(ctx, raw.p, npoints, stride);
-    } catch (...) {
-      raw.release();
-      throw;
-    }
-    raw.release();
+    if (!ctx->shards.empty()) return sharded_set_bases(ctx, affine, npoints, stride, false, false);
+    set_bases_host(ctx, affine, npoints, stride, false);
   });
 }
 
@@ -671,23 +865,9 @@ RustError mi355_msm_set_bases_serialized(mi355_msm_ctx* ctx, const void* records
   return guarded([&] {
     if (!ctx) bad_arg("null context");
     if (npoints && !records) bad_arg("null records pointer");
-    ensure_device(ctx);
     const size_t stride = 2 * coord_bytes(ctx->curve);
-    DevBuf raw;
-    ctx->bases_serialized = true;
-    try {
-      if (npoints) {
-        raw.reserve(npoints * stride);
-        HIP_OK(hipMemcpy(raw.p, records, npoints * stride, hipMemcpyHostToDevice));
-      }
-      set_bases_device(ctx, raw.p, npoints, stride);
-    } catch (...) {
-      ctx->bases_serialized = false;
-      raw.release();
-      throw;
-    }
-    ctx->bases_serialized = false;
-    raw.release();
+    if (!ctx->shards.empty()) return sharded_set_bases(ctx, records, npoints, stride, true, false);
+    set_bases_host(ctx, records, npoints, stride, true);
   });
 }
 
@@ -703,7 +883,11 @@ RustError mi355_msm_point_to_serialized(int curve, const void* projective, void*
       uint8_t* out = (uint8_t*)out_record;
       memset(out, 0, 2 * CB);
       if (xyzz_is_inf<E>(p)) {
-        out[2 * CB - 1] = 0x40;   // SWFlags::Infinity
+        // arkworks writes GroupAffine::zero() = (0, 1, infinity) -- x = 0, y = 1 in normal form (for G2: y.c0 = 1) -- and ORs
+        // SWFlags::Infinity into the last byte (P1B nickray driver/algebra/ec/src/models/short_weierstrass_jacobian.rs:154-156,
+        // 827-835)
+        out[CB] = 1;
+        out[2 * CB - 1] |= 0x40;
         return;
       }
       typename E::T t, ti, zzi, zzzi, x, y;
@@ -725,6 +909,7 @@ RustError mi355_msm_set_bases_device(mi355_msm_ctx* ctx, const void* d_affine, s
   return guarded([&] {
     if (!ctx) bad_arg("null context");
     if (npoints && !d_affine) bad_arg("null bases pointer");
+    if (!ctx->shards.empty()) return sharded_set_bases(ctx, d_affine, npoints, stride, false, true);
     // the producer (e.g. torch) may have written the buffer on another stream: make it visible first
     ensure_device(ctx);
     HIP_OK(hipDeviceSynchronize());
@@ -736,16 +921,8 @@ RustError mi355_msm_run(mi355_msm_ctx* ctx, void* out, const void* scalars, size
   return guarded([&] {
     if (!ctx) bad_arg("null context");
     if (npoints * batches && !scalars) bad_arg("null scalars pointer");
-    ensure_device(ctx);
-    size_t bytes = npoints * batches * 32;
-    ctx->scalars.reserve(bytes ? bytes : 32);
-    if (!ctx->copy_stream) {
-      HIP_OK(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
-      for (auto& ev : ctx->copy_ev) HIP_OK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    }
-    HostBatches hb{(const uint8_t*)scalars, ctx->scalars.as<uint8_t>(), npoints * 32, ctx->copy_stream, {ctx->copy_ev[0], ctx->copy_ev[1]},
-                   ctx->copy_ev[2]};
-    run_device(ctx, out, ctx->scalars.p, npoints, batches, ctx->own_stream, &hb);
+    if (!ctx->shards.empty()) return sharded_run(ctx, out, scalars, npoints, batches, false, nullptr);
+    run_host(ctx, out, scalars, npoints, batches, npoints);
   });
 }
 
@@ -754,7 +931,8 @@ RustError mi355_msm_run_device(mi355_msm_ctx* ctx, void* out, const void* d_scal
   return guarded([&] {
     if (!ctx) bad_arg("null context");
     if (npoints * batches && !d_scalars) bad_arg("null scalars pointer");
-    run_device(ctx, out, d_scalars, npoints, batches, (hipStream_t)stream);
+    if (!ctx->shards.empty()) return sharded_run(ctx, out, d_scalars, npoints, batches, true, (hipStream_t)stream);
+    run_device(ctx, out, d_scalars, npoints, batches, npoints, (hipStream_t)stream);
   });
 }
 
@@ -762,6 +940,18 @@ RustError mi355_msm_set_option(mi355_msm_ctx* ctx, const char* key, long value) 
   return guarded([&] {
     if (!ctx || !key) bad_arg("null argument");
     std::string k(key);
+    if (!ctx->shards.empty() && k != "combine") {
+      for (mi355_msm_ctx* sh : ctx->shards) {
+        RustError e = mi355_msm_set_option(sh, key, value);
+        if (e.code) {
+          std::string m = e.message ? e.message : "";
+          free(e.message);
+          throw HipFailure(e.code, m);
+        }
+      }
+      return;
+    }
+    ctx->fitted_chunk = 0;   // options change the plan, hence the buffer sizes
     if (k == "window_bits") {
       if (value != 0 && (value < 2 || value > 24)) bad_arg("window_bits %ld out of range [2, 24]", value);
       if (ctx->pre_c && value != 0 && (uint32_t)value != ctx->pre_c)
@@ -786,6 +976,17 @@ RustError mi355_msm_set_option(mi355_msm_ctx* ctx, const char* key, long value) 
       ctx->opt_precompute = value != 0;   // takes effect at the next set_bases
     } else if (k == "scalars_montgomery") {
       ctx->opt_scalars_montgomery = value != 0;
+    } else if (k == "combine") {
+      if (value < 0 || value > 2) bad_arg("combine %ld out of range [0, 2]", value);
+      ctx->opt_combine = value;
+    } else if (k == "mem_limit") {
+      // test hook: size chunks as if at most `value` bytes of device memory were available for the work buffers
+      if (value < 0) bad_arg("mem_limit must be >= 0");
+      ctx->opt_mem_limit = value;
+      ctx->chunk_cap = 0;
+    } else if (k == "inject_alloc_failures") {
+      // test hook: the next `value` device allocations made by the calling thread fail with hipErrorOutOfMemory
+      g_inject_alloc_failures = value;
     } else {
       bad_arg("unknown option '%s'", key);
     }
@@ -795,8 +996,15 @@ RustError mi355_msm_set_option(mi355_msm_ctx* ctx, const char* key, long value) 
 RustError mi355_msm_last_timings(mi355_msm_ctx* ctx, float* ms, uint64_t* info) {
   return guarded([&] {
     if (!ctx) bad_arg("null context");
+    if (!ctx->shards.empty()) {
+      // shards run concurrently: report the slowest shard per stage, and the plan of shard 0
+      memset(ctx->last_ms, 0, sizeof ctx->last_ms);
+      for (mi355_msm_ctx* sh : ctx->shards)
+        for (int i = 0; i < MI355_T_COUNT; i++) ctx->last_ms[i] = std::max(ctx->last_ms[i], sh->last_ms[i]);
+      memcpy(ctx->last_info, ctx->shards[0]->last_info, sizeof ctx->last_info);
+    }
     if (ms) memcpy(ms, ctx->last_ms, sizeof ctx->last_ms);
-    if (info) memcpy(info, ctx->last_info, 6 * sizeof(uint64_t));
+    if (info) memcpy(info, ctx->last_info, sizeof ctx->last_info);
   });
 }
 
@@ -804,10 +1012,43 @@ RustError mi355_msm_query(mi355_msm_ctx* ctx, const char* key, uint64_t* value) 
   return guarded([&] {
     if (!ctx || !key || !value) bad_arg("null argument");
     std::string k(key);
+    if (k == "shards") {
+      *value = ctx->shards.size();
+      return;
+    }
+    if (k == "rccl_exchanges") {
+      *value = ctx->rccl_exchanges;
+      return;
+    }
+    if (!ctx->shards.empty()) {
+      // counters add up over the shards; "twisted_edwards" is 1 only if every shard runs on that path
+      uint64_t sum = 0, all = 1;
+      for (mi355_msm_ctx* sh : ctx->shards) {
+        uint64_t v = 0;
+        RustError e = mi355_msm_query(sh, key, &v);
+        if (e.code) {
+          std::string m = e.message ? e.message : "";
+          free(e.message);
+          throw HipFailure(e.code, m);
+        }
+        sum += v;
+        all &= (v != 0);
+      }
+      *value = (k == "twisted_edwards") ? all : ((k == "table_levels" || k == "table_window_bits") ? sum / ctx->shards.size() : sum);
+      return;
+    }
     if (k == "twisted_edwards")
       *value = ctx->te_active ? 1 : 0;
     else if (k == "twisted_edwards_fallbacks")
       *value = ctx->te_fallbacks;
+    else if (k == "twisted_edwards_demotions")
+      *value = ctx->te_demotions;
+    else if (k == "oom_backoffs")
+      *value = ctx->oom_backoffs;
+    else if (k == "chunk_cap")
+      *value = ctx->chunk_cap;
+    else if (k == "device")
+      *value = (uint64_t)ctx->device;
     else if (k == "bases")
       *value = ctx->nbases;
     else if (k == "table_levels")
@@ -823,7 +1064,7 @@ RustError mi355_msm_query(mi355_msm_ctx* ctx, const char* key, uint64_t* value) 
 
 RustError mi355_msm(int curve, void* out, const void* affine, size_t npoints, const void* scalars, size_t ffi_affine_sz) {
   mi355_msm_ctx* ctx = nullptr;
-  RustError e = mi355_msm_create(&ctx, curve, -1);
+  RustError e = mi355_msm_create_env(&ctx, curve);
   if (e.code) return e;
   e = mi355_msm_set_bases(ctx, affine, npoints, ffi_affine_sz);
   if (!e.code) e = mi355_msm_run(ctx, out, scalars, npoints, 1);
@@ -889,12 +1130,19 @@ RustError mi355_msm_plan(int curve, size_t npoints, int precompute, const long* 
     out[6] = merge_levels;
     out[7] = reduce_levels;
     out[8] = p.keybits;
-    // device bytes of the per-run work buffers (keys/vals x2, buckets, slots x2, reduce x4)
-    out[9] = p.entries * 16 + (uint64_t)p.bucket_windows * p.half * 224 * el + 2 * (2ull * p.nlanes) * (224 * el + 4) +
-             4ull * p.bucket_windows * p.T0 * 224 * el;
+    // device bytes of the per-run work buffers (entry buffers x2, grouping scratch, buckets, slots x2, reduce x4)
+    out[9] = work_bytes(p, el);
   });
 }
 
-const char* mi355_msm_version(void) { return "mi355-msm 0.1 (gfx950)"; }
+RustError mi355_msm_shard_bounds(size_t npoints, int nshards, int shard, size_t* lo, size_t* hi) {
+  return guarded([&] {
+    if (!lo || !hi) bad_arg("null output");
+    if (nshards < 1 || shard < 0 || shard >= nshards) bad_arg("shard %d of %d", shard, nshards);
+    shard_bounds(npoints, (size_t)nshards, (size_t)shard, *lo, *hi);
+  });
+}
+
+const char* mi355_msm_version(void) { return "mi355-msm 0.2 (gfx950)"; }
 
 }  // extern "C"

@@ -1,15 +1,14 @@
-// msm_kernels.cuh -- the gfx950 kernels of the Pippenger pipeline.
+// msm_kernels.hpp -- the gfx950 kernels of the Pippenger pipeline.
 //
 //   k_convert_bases   arkworks Affine image (stride bytes, R = 2^384)  ->  device Affine (112 B, radix 2^28, R = 2^392)
-//   k_digits          256-bit scalars -> signed c-bit digits -> (bucket key, base index | sign) entries
-//   (rocPRIM radix sort of the entries by key -- scaffolding, see msm_engine.hip)
+//   (partition.hpp)   256-bit scalars -> signed c-bit digits -> (bucket key, base index | sign) entries grouped by key
 //   k_accumulate      sorted-range walk: each lane owns K consecutive sorted entries and mixed-adds their
 //                     bases; finished buckets are stored once, run fragments that cross a lane boundary
 //                     go to per-lane head/tail slots
 //   k_segreduce       merges the slot fragments (same walk, full XYZZ add), recursively
 //   k_bucket_reduce   sum_b b * bucket[b] per window by chunked running sums, recursively
-//   k_te_convert      short-Weierstrass base records -> twisted-Edwards records (BLS12-377 G1 fast path, te.cuh)
-// The three walking kernels are generic over a group-law policy (laws.cuh): XYZZ for every curve, extended twisted Edwards
+//   k_te_convert      short-Weierstrass base records -> twisted-Edwards records (BLS12-377 G1 fast path, te.hpp)
+// The three walking kernels are generic over a group-law policy (laws.hpp): XYZZ for every curve, extended twisted Edwards
 // for BLS12-377 G1.
 //
 // Reference behaviour covered: digit extraction SPK msm/pippenger.cuh:116-123, signed digits
@@ -20,9 +19,9 @@
 // (DESIGN.md): the walk is balanced per ENTRY, not per bucket, so skewed scalar distributions
 // (one hot bucket, the sparse top window) cost the same as uniform ones.
 #pragma once
-#include "curve.cuh"
-#include "laws.cuh"
-#include "msm_types.cuh"
+#include "curve.hpp"
+#include "laws.hpp"
+#include "msm_types.hpp"
 
 namespace msm {
 
@@ -92,11 +91,10 @@ __device__ __forceinline__ void seg_flush(const SegOutT<T>& o, uint32_t t, uint3
 
 // The hot kernel.  Lane t walks sorted entries [t*K, (t+1)*K): ~K mixed adds, one bucket store per run.
 // The next base is fetched before the current add so the gather latency hides under ~5k VALU ops.
-// G = the group-law policy (laws.cuh); `flags[1]` is raised when the law reports a result it could not compute.
+// G = the group-law policy (laws.hpp); `flags[1]` is raised when the law reports a result it could not compute.
 template <class G>
-__global__ void __launch_bounds__(256, G::ACC_WAVES) k_accumulate(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
-                                                    uint32_t n_entries, uint32_t K, uint32_t sentinel,
-                                                    const typename G::BaseDev* __restrict__ bases,
+__global__ void __launch_bounds__(256, G::ACC_WAVES) k_accumulate(const uint2* __restrict__ entries, const uint32_t* __restrict__ n_real,
+                                                    uint32_t K, const typename G::BaseDev* __restrict__ bases,
                                                     SegOutT<typename G::T> out, uint32_t nlanes, uint32_t* __restrict__ flags) {
   using E = typename G::E;
   const uint32_t t = blockIdx.x * 256 + threadIdx.x;
@@ -104,42 +102,34 @@ __global__ void __launch_bounds__(256, G::ACC_WAVES) k_accumulate(const uint32_t
   typename E::Md md;
   out.slot_keys[2 * (size_t)t] = KEY_NONE;
   out.slot_keys[2 * (size_t)t + 1] = KEY_NONE;
-  // 32-bit positions: a chunk never has 2^32 entries (the engine checks), and every VGPR counts in this kernel
+  // 32-bit positions: a chunk never has 2^32 entries (the engine checks), and every VGPR counts in this kernel.
+  // Entries are (value = base index | sign << 31, key) pairs sorted by key (partition.hpp); their count lives on the device
+  // because zero digits produce no entry.
+  const uint32_t n_entries = *n_real;
   const uint64_t beg64 = (uint64_t)t * K;
   if (beg64 >= n_entries) return;
   const uint32_t beg = (uint32_t)beg64;
   const uint32_t end = (n_entries - beg > K) ? beg + K : n_entries;
 
-  // Software pipeline: entry indices run TWO iterations ahead and the base gather ONE iteration ahead, so the gather
-  // address never waits on an index load (a dependent load pair would park the wave for ~1 us per add).
-  uint32_t key_c = keys[beg], val_c = vals[beg];
-  uint32_t key_n = sentinel, val_n = 0;
-  if (end - beg > 1) {
-    key_n = keys[beg + 1];
-    val_n = vals[beg + 1];
-  }
+  // Software pipeline: entries run TWO iterations ahead and the base gather ONE iteration ahead, so the gather
+  // address never waits on an entry load (a dependent load pair would park the wave for ~1 us per add).
+  uint2 ent_c = entries[beg], ent_n = make_uint2(0, KEY_NONE);
+  if (end - beg > 1) ent_n = entries[beg + 1];
   // (G::PREFETCH_BASE = false -- G2, whose accumulator alone is 112 VGPRs -- gathers the base at its point of use instead)
   typename G::Base p_c;
-  if (G::PREFETCH_BASE && key_c != sentinel) p_c = bases[val_c & IDX_MASK].p;
+  if (G::PREFETCH_BASE) p_c = bases[ent_c.x & IDX_MASK].p;
 
   uint32_t cur = KEY_NONE;
   bool first = true, fresh = true, bad = false;
   XyzzT<typename G::T> acc;
   G::set_identity(acc);
   for (uint32_t e = beg; e < end; e++) {
-    const uint32_t key = key_c, val = val_c;
-    if (key == sentinel) break;  // sorted: nothing but sentinels from here on
+    const uint32_t key = ent_c.y, val = ent_c.x;
     if (!G::PREFETCH_BASE) p_c = bases[val & IDX_MASK].p;
     const typename G::Base p = p_c;
-    key_c = key_n;
-    val_c = val_n;
-    if (G::PREFETCH_BASE && end - e > 1 && key_c != sentinel) p_c = bases[val_c & IDX_MASK].p;
-    if (end - e > 2) {
-      key_n = keys[e + 2];
-      val_n = vals[e + 2];
-    } else {
-      key_n = sentinel;
-    }
+    ent_c = ent_n;
+    if (G::PREFETCH_BASE && end - e > 1) p_c = bases[ent_c.x & IDX_MASK].p;
+    if (end - e > 2) ent_n = entries[e + 2];
     if (key != cur) {
       if (cur != KEY_NONE) {
         seg_flush(out, t, nlanes, cur, acc, first, false);
@@ -166,9 +156,8 @@ __global__ void __launch_bounds__(256, G::ACC_WAVES) k_accumulate(const uint32_t
 // back as one contiguous run (same-wave LDS traffic is ordered, so no barrier; slots are padded against bank conflicts).
 // All lanes of a wave stay in the loop until the whole wave is done, because the quad needs all four of them.
 template <class G>
-__global__ void __launch_bounds__(256, G::ACC_WAVES) k_accumulate_coop(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
-                                                         uint32_t n_entries, uint32_t K, uint32_t sentinel,
-                                                         const typename G::BaseDev* __restrict__ bases,
+__global__ void __launch_bounds__(256, G::ACC_WAVES) k_accumulate_coop(const uint2* __restrict__ entries, const uint32_t* __restrict__ n_real,
+                                                         uint32_t K, const typename G::BaseDev* __restrict__ bases,
                                                          SegOutT<typename G::T> out, uint32_t nlanes, uint32_t* __restrict__ flags) {
   using E = typename G::E;
   using Base = typename G::Base;
@@ -185,21 +174,24 @@ __global__ void __launch_bounds__(256, G::ACC_WAVES) k_accumulate_coop(const uin
     out.slot_keys[2 * (size_t)t] = KEY_NONE;
     out.slot_keys[2 * (size_t)t + 1] = KEY_NONE;
   }
+  const uint32_t n_entries = *n_real;   // zero digits produce no entry: the count of real ones lives on the device
   const uint64_t beg64 = (uint64_t)t * K;
   const bool has_work = lane_ok && beg64 < n_entries;
   const uint32_t beg = has_work ? (uint32_t)beg64 : 0;
   const uint32_t end = has_work ? ((n_entries - beg > K) ? beg + K : n_entries) : 0;
 
-  uint32_t key_c = sentinel, val_c = 0, key_n = sentinel, val_n = 0;
+  uint32_t key_c = KEY_NONE, val_c = 0, key_n = KEY_NONE, val_n = 0;
   if (end > beg) {
-    key_c = keys[beg];
-    val_c = vals[beg];
+    const uint2 e0 = entries[beg];
+    key_c = e0.y;
+    val_c = e0.x;
     if (end - beg > 1) {
-      key_n = keys[beg + 1];
-      val_n = vals[beg + 1];
+      const uint2 e1 = entries[beg + 1];
+      key_n = e1.y;
+      val_n = e1.x;
     }
   }
-  bool alive = key_c != sentinel;
+  bool alive = end > beg;
 
   // The quad's four gathers: record i belongs to quad lane i; a lane without a next entry asks for record 0.
   // (Twelve named registers and macros rather than an array and lambdas: hipcc leaves a loop-carried array in scratch.)
@@ -240,6 +232,12 @@ __global__ void __launch_bounds__(256, G::ACC_WAVES) k_accumulate_coop(const uin
       if (SECT == 3) {
         MSM_COOP_PUT(0, 2, q02); MSM_COOP_PUT(1, 2, q12); MSM_COOP_PUT(2, 2, q22); MSM_COOP_PUT(3, 2, q32);
       }
+      // The pieces cross lanes of ONE wave: LDS operations of a wave execute in order, so no s_barrier is needed -- but the
+      // compiler must not move the read-back above the stores, nor the next iteration's stores above this read-back.
+      // Wavefront-scope fences + wave_barrier are zero-instruction scheduling barriers that say exactly that.
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       const uint4* mine = reinterpret_cast<const uint4*>(lds + threadIdx.x * LS);
       uint32_t* dst = reinterpret_cast<uint32_t*>(&p);
 #pragma unroll
@@ -250,18 +248,20 @@ __global__ void __launch_bounds__(256, G::ACC_WAVES) k_accumulate_coop(const uin
         if (4 * q + 2 < (int)(sizeof(Base) / 4)) dst[4 * q + 2] = v.z;
         if (4 * q + 3 < (int)(sizeof(Base) / 4)) dst[4 * q + 3] = v.w;
       }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
     const uint32_t key = key_c, val = val_c, e = beg + k;
     const bool add_now = alive;
     key_c = key_n;
     val_c = val_n;
-    alive = add_now && (end - e > 1) && key_c != sentinel;
+    alive = add_now && (end - e > 1);
     MSM_COOP_ISSUE(val_c, alive);
     if (add_now && end - e > 2) {
-      key_n = keys[e + 2];
-      val_n = vals[e + 2];
-    } else {
-      key_n = sentinel;
+      const uint2 e2 = entries[e + 2];
+      key_n = e2.y;
+      val_n = e2.x;
     }
     if (add_now) {
       if (key != cur) {
@@ -450,7 +450,7 @@ __global__ void __launch_bounds__(256) k_pre_normalize(const XyzzDevT<typename E
 }
 
 // ------------------------------------------------------------------------------------------------
-// Short-Weierstrass device records -> twisted-Edwards records (te.cuh), Montgomery's trick over J consecutive points per
+// Short-Weierstrass device records -> twisted-Edwards records (te.hpp), Montgomery's trick over J consecutive points per
 // lane: the forward pass stores the running products of the map's denominators, the backward pass peels one inverse per
 // point.  Points without an image are counted in flags[0] (the engine then keeps the base set on the XYZZ path) and get a
 // harmless filler; bases flagged infinite are never gathered.

@@ -1,6 +1,6 @@
-// msm_types.cuh -- device data layouts shared by the kernels and the host orchestration.
+// msm_types.hpp -- device data layouts shared by the kernels and the host orchestration.
 #pragma once
-#include "curve.cuh"
+#include "curve.hpp"
 
 namespace msm {
 

@@ -1,0 +1,528 @@
+// partition.hpp -- bucket grouping: scalars -> signed c-bit digits -> entries grouped by (window, bucket),
+// as hand-written gfx950 kernels.  Replaces the library radix sort the first round used as scaffolding.
+//
+// What the reference does here: the CUB path of Matter Labs (ML msm.cu:229-330, "sorting is the bottleneck",
+// P1A matter-labs/README.md:62-68) and yrrid's own partition + sort (CMB Partition1024.cu:157-243,
+// Partition4096.cu:351-433, SortCounts.cu:54-185).  This is neither: an MSD partition whose FIRST level is fused with
+// the digit extraction, so the W x N (key, value) pairs never exist as an unsorted 7-GB array that a sort has to re-read.
+//
+//   L1   tile = 8192 consecutive scalars, held in registers by a 1024-thread block for all W windows (32 B in, once).
+//        k_l1_hist     digits of the tile -> per-tile histogram over the level-1 bins (window, top HB bits of the bucket),
+//                      written as one row of a [tiles x bins] matrix (no atomics: deterministic offsets)
+//        k_l1_scan_*   column scan of the matrix -> the offset of every (tile, bin) run, the bin (= segment) table
+//        k_l1_scatter  digits again (cheaper than keeping 7 GB of them), LDS multisplit of the tile's 8192 entries of one
+//                      window into its 512 bins, flushed as ~16-entry / 128-B contiguous runs of u64 entries
+//                      (value = base index | sign << 31 in the low word, remaining bucket bits in the high word)
+//   Pn   one or more generic passes over the segments the previous level produced, RB more bucket bits each:
+//        k_pass_hist / k_pass_scan / k_pass_scatter -- a segment is cut into sub-jobs of <= SUBJOB entries, one block each, so
+//        a skewed input (all scalars equal: one segment holds everything) is spread over the chip like a uniform one; offsets
+//        again come from a (sub-job x bin) histogram matrix, not from atomics.  The last pass writes the full key into the
+//        high word: the output is the (key, value) array the accumulation walks, fully sorted by key.
+//
+// Zero digits and bases flagged infinite produce NO entry (the count of real entries lives in device memory and the
+// accumulation reads it), so there are no sentinel keys any more.
+// With precomputed tables all windows share one bucket set: level-1 bins are then numbered bucket-major (top bits, then
+// window), which makes the W per-window runs of a bucket range contiguous -- the same kernels, one more pass.
+//
+// Measured inputs to this design (tools/ubench_atomics.hip, profiles/r02_ubench_atomics.txt): device-scope atomics top out
+// at 27 G/s (so per-tile claims by atomics would cost as much as the data movement), scattered stores need >= 64-B runs
+// (16 B: 0.36 TB/s, 64 B: 3.2 TB/s, 128 B: 5.2 TB/s).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <algorithm>
+
+#include "digits.hpp"
+#include "partition_plan.hpp"
+
+namespace msm {
+
+// ---- block-wide exclusive scan of one value per thread (blockDim.x a multiple of 64, <= 1024) --------------------------
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t u = __shfl_up(v, d, 64);
+    if ((int)(threadIdx.x & 63) >= d) v += u;
+  }
+  return v;
+}
+// tmp: >= 17 words of LDS.  Returns the exclusive prefix of v; total of the block in `total`.  Ends with a barrier.
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* tmp, uint32_t& total) {
+  const uint32_t incl = wave_incl_scan(v);
+  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+  if (lane == 63) tmp[wave] = incl;
+  __syncthreads();
+  if (wave == 0) {
+    uint32_t w = lane < nw ? tmp[lane] : 0;
+    const uint32_t wi = wave_incl_scan(w);
+    if (lane < nw) tmp[lane] = wi - w;
+    if (lane == nw - 1) tmp[16] = wi;
+  }
+  __syncthreads();
+  const uint32_t r = tmp[wave] + incl - v;
+  total = tmp[16];
+  __syncthreads();
+  return r;
+}
+
+// ---- digits of one scalar, window after window --------------------------------------------------------------------------
+struct ScalarDigits {
+  uint32_t s[8];
+  uint32_t carry;
+};
+// Next signed digit (CMB ProcessSignedDigits.cu:118-151 semantics): |d| in [0, 2^(c-1)], neg = the digit is negative.
+__device__ __forceinline__ void next_digit(ScalarDigits& st, uint32_t c, uint32_t half, uint32_t wmask, uint32_t& mag, bool& neg) {
+  const uint32_t v = (st.s[0] & wmask) + st.carry;
+#pragma unroll
+  for (int j = 0; j < 7; j++) st.s[j] = (st.s[j] >> c) | (st.s[j + 1] << (32 - c));
+  st.s[7] >>= c;
+  neg = v > half;
+  mag = neg ? (1u << c) - v : v;
+  st.carry = neg ? 1u : 0u;
+}
+
+template <class FR, bool MONT>
+__device__ __forceinline__ void load_scalar(ScalarDigits& st, const uint32_t* __restrict__ scalars, uint32_t i) {
+  const uint4* sp = reinterpret_cast<const uint4*>(scalars) + 2 * (size_t)i;
+  const uint4 lo = sp[0], hi = sp[1];
+  uint32_t s[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+  if (MONT) fr_from_montgomery<FR>(s);
+#pragma unroll
+  for (int j = 0; j < 8; j++) st.s[j] = s[j];
+  st.carry = 0;
+}
+
+// Level-1 bin of (window w, bucket b): window-major normally; bucket-major with shared buckets, so that the W runs of one
+// bucket range are neighbours and form ONE segment for the next pass.
+__device__ __forceinline__ uint32_t l1_bin(const PartPlan& p, uint32_t w, uint32_t bucket) {
+  const uint32_t hi = bucket >> p.lb;
+  return p.shared ? hi * p.windows + w : w * p.b1 + hi;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// L1 histogram: one block per tile, matrix row = the tile's entry count per level-1 bin.
+template <class FR, bool MONT>
+__global__ void __launch_bounds__(PART_THREADS) k_l1_hist(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ inf, PartPlan p,
+                                                          uint32_t* __restrict__ matrix) {
+  extern __shared__ uint32_t hist[];   // nbins
+  for (uint32_t b = threadIdx.x; b < p.nbins; b += PART_THREADS) hist[b] = 0;
+  __syncthreads();
+  const uint32_t wmask = (1u << p.c) - 1;
+  const uint32_t i0 = blockIdx.x * PART_TILE;
+#pragma unroll 1
+  for (int k = 0; k < PART_PER_THREAD; k++) {
+    const uint32_t i = i0 + threadIdx.x + k * PART_THREADS;
+    if (i >= p.n) break;
+    ScalarDigits st;
+    load_scalar<FR, MONT>(st, scalars, i);
+    const bool dead0 = p.table_stride ? false : inf[p.idx0 + i] != 0;
+    for (uint32_t w = 0; w < p.windows; w++) {
+      uint32_t mag;
+      bool neg;
+      next_digit(st, p.c, p.half, wmask, mag, neg);
+      bool dead = dead0;
+      if (p.table_stride) dead = inf[p.idx0 + i + w * p.table_stride] != 0;
+      if (mag != 0 && !dead) atomicAdd(&hist[l1_bin(p, w, mag - 1)], 1u);
+    }
+  }
+  __syncthreads();
+  uint32_t* row = matrix + (size_t)blockIdx.x * p.nbins;
+  for (uint32_t b = threadIdx.x; b < p.nbins; b += PART_THREADS) row[b] = hist[b];
+}
+
+// Column scan of the [ntiles x nbins] matrix, three small kernels:
+//   A  partial[g][b] = sum of the tiles of group g
+//   B  (one block) exclusive scan over groups, then over bins: gbase[g][b] = first position of group g's entries of bin b;
+//      writes the segment table (start, len, key_base), the sub-job prefix for the next pass and the entry total
+//   C  in place: matrix[t][b] = position of tile t's run of bin b
+__global__ void __launch_bounds__(256) k_l1_scan_a(const uint32_t* __restrict__ matrix, PartPlan p, uint32_t* __restrict__ partial) {
+  const uint32_t b = blockIdx.x * 256 + threadIdx.x, g = blockIdx.y;
+  if (b >= p.nbins) return;
+  const uint32_t t0 = g * p.tiles_per_group;
+  const uint32_t t1 = min(p.ntiles, t0 + p.tiles_per_group);
+  uint32_t sum = 0;
+  for (uint32_t t = t0; t < t1; t++) sum += matrix[(size_t)t * p.nbins + b];
+  partial[(size_t)g * p.nbins + b] = sum;
+}
+
+__global__ void __launch_bounds__(1024) k_l1_scan_b(uint32_t* __restrict__ partial, PartPlan p, PartSeg* __restrict__ segs,
+                                                    uint32_t* __restrict__ subjob_first, uint32_t* __restrict__ totals) {
+  __shared__ uint32_t tmp[32];
+  __shared__ uint32_t carry_pos, carry_sj;
+  if (threadIdx.x == 0) carry_pos = carry_sj = 0;
+  __syncthreads();
+  for (uint32_t b0 = 0; b0 < p.nbins; b0 += 1024) {
+    const uint32_t b = b0 + threadIdx.x;
+    // the 64 group sums of this bin: all loads in flight at once (a load-store-load chain on one array would serialise on
+    // ~1 us of latency per step, 0.5 ms per launch), scanned in registers, written back below
+    uint32_t gv[PART_SCAN_GROUPS];
+    uint32_t col = 0;
+    if (b < p.nbins) {
+#pragma unroll
+      for (int g = 0; g < PART_SCAN_GROUPS; g++) gv[g] = partial[(size_t)g * p.nbins + b];
+#pragma unroll
+      for (int g = 0; g < PART_SCAN_GROUPS; g++) {
+        const uint32_t v = gv[g];
+        gv[g] = col;   // exclusive over groups
+        col += v;
+      }
+    }
+    uint32_t tot, tot_sj;
+    const uint32_t before = block_excl_scan(col, tmp, tot);
+    const uint32_t nsj = (col + PART_SUBJOB - 1) / PART_SUBJOB;
+    const uint32_t sj_before = block_excl_scan(nsj, tmp, tot_sj);
+    const uint32_t base = carry_pos, base_sj = carry_sj;
+    if (b < p.nbins) {
+      const uint32_t start = base + before;
+#pragma unroll
+      for (int g = 0; g < PART_SCAN_GROUPS; g++) partial[(size_t)g * p.nbins + b] = gv[g] + start;
+      // key bits resolved so far: window-major (w * half + hi << lb), or just hi << lb with shared buckets
+      uint32_t key_base;
+      if (p.shared)
+        key_base = (b / p.windows) << p.lb;
+      else
+        key_base = (b / p.b1) * p.half + ((b % p.b1) << p.lb);
+      segs[b] = PartSeg{start, col, key_base, 0};
+      subjob_first[b] = base_sj + sj_before;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      carry_pos = base + tot;
+      carry_sj = base_sj + tot_sj;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    subjob_first[p.nbins] = carry_sj;
+    totals[0] = carry_pos;   // real entries
+    totals[1] = carry_sj;    // sub-jobs of the next pass
+  }
+}
+
+__global__ void __launch_bounds__(256) k_l1_scan_c(uint32_t* __restrict__ matrix, PartPlan p, const uint32_t* __restrict__ partial) {
+  const uint32_t b = blockIdx.x * 256 + threadIdx.x, g = blockIdx.y;
+  if (b >= p.nbins) return;
+  const uint32_t t0 = g * p.tiles_per_group;
+  const uint32_t t1 = min(p.ntiles, t0 + p.tiles_per_group);
+  uint32_t run = partial[(size_t)g * p.nbins + b];
+  for (uint32_t t = t0; t < t1; t++) {
+    const size_t at = (size_t)t * p.nbins + b;
+    const uint32_t v = matrix[at];
+    matrix[at] = run;
+    run += v;
+  }
+}
+
+// With shared buckets the segments of the next pass are the b1 bucket ranges, each the union of `windows` neighbouring bins.
+__global__ void __launch_bounds__(256) k_l1_merge_shared(const PartSeg* __restrict__ bins, PartPlan p, PartSeg* __restrict__ segs,
+                                                         uint32_t* __restrict__ subjob_first, uint32_t* __restrict__ totals) {
+  // one block; b1 <= 512 segments
+  __shared__ uint32_t tmp[32];
+  for (uint32_t h0 = 0; h0 < p.b1; h0 += 256) {
+    const uint32_t h = h0 + threadIdx.x;
+    uint32_t len = 0, start = 0;
+    if (h < p.b1) {
+      start = bins[h * p.windows].start;
+      for (uint32_t w = 0; w < p.windows; w++) len += bins[h * p.windows + w].len;
+    }
+    const uint32_t nsj = (len + PART_SUBJOB - 1) / PART_SUBJOB;
+    uint32_t tot;
+    const uint32_t before = block_excl_scan(nsj, tmp, tot);
+    const uint32_t base = h0 == 0 ? 0 : subjob_first[h0];
+    if (h < p.b1) {
+      segs[h] = PartSeg{start, len, h << p.lb, 0};
+      subjob_first[h] = base + before;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) subjob_first[min(h0 + 256, p.b1)] = base + tot;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) totals[1] = subjob_first[p.b1];
+}
+
+// L1 scatter: one block per tile; the tile's scalars stay in registers while the windows are processed one after the other.
+// LDS: stage (8192 x u64) + bin of every staged entry (u16) + three (b1 + 1)-word arrays.
+template <class FR, bool MONT>
+__global__ void __launch_bounds__(PART_THREADS) k_l1_scatter(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ inf, PartPlan p,
+                                                             const uint32_t* __restrict__ matrix, uint2* __restrict__ out) {
+  __shared__ uint2 stage[PART_TILE];
+  __shared__ uint16_t sbin[PART_TILE];
+  __shared__ uint32_t offs[1 << PART_MAX_HB], cnt[1 << PART_MAX_HB], tstart[(1 << PART_MAX_HB) + 1];
+  __shared__ uint32_t tmp[32];
+  const uint32_t wmask = (1u << p.c) - 1, lowmask = (1u << p.lb) - 1;
+  const uint32_t i0 = blockIdx.x * PART_TILE;
+  ScalarDigits st[PART_PER_THREAD];
+  uint32_t alive = 0;     // bit k: scalar k exists and (without tables) its base is not flagged infinite
+#pragma unroll
+  for (int k = 0; k < PART_PER_THREAD; k++) {
+    const uint32_t i = i0 + threadIdx.x + k * PART_THREADS;
+    if (i < p.n) {
+      load_scalar<FR, MONT>(st[k], scalars, i);
+      if (p.table_stride || inf[p.idx0 + i] == 0) alive |= 1u << k;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; j++) st[k].s[j] = 0;
+      st[k].carry = 0;
+    }
+  }
+  const uint32_t* row = matrix + (size_t)blockIdx.x * p.nbins;
+  for (uint32_t w = 0; w < p.windows; w++) {
+    for (uint32_t b = threadIdx.x; b < p.b1; b += PART_THREADS) {
+      cnt[b] = 0;
+      offs[b] = row[p.shared ? b * p.windows + w : w * p.b1 + b];
+    }
+    __syncthreads();
+    uint32_t where[PART_PER_THREAD];   // bin << 16 | rank in the tile's bin; 0xffffffff = no entry
+    uint2 ent[PART_PER_THREAD];
+#pragma unroll
+    for (int k = 0; k < PART_PER_THREAD; k++) {
+      uint32_t mag;
+      bool neg;
+      next_digit(st[k], p.c, p.half, wmask, mag, neg);
+      const uint32_t i = i0 + threadIdx.x + k * PART_THREADS;
+      bool ok = ((alive >> k) & 1) && mag != 0;
+      const uint32_t idx = p.idx0 + i + w * p.table_stride;
+      if (ok && p.table_stride) ok = inf[idx] == 0;
+      where[k] = 0xffffffffu;
+      if (ok) {
+        const uint32_t bucket = mag - 1, hi = bucket >> p.lb;
+        const uint32_t rank = atomicAdd(&cnt[hi], 1u);
+        where[k] = (hi << 16) | rank;
+        ent[k] = make_uint2(idx | (neg ? 0x80000000u : 0u), bucket & lowmask);
+      }
+    }
+    __syncthreads();
+    {
+      // exclusive scan of the tile's bin counts (b1 <= 512 <= blockDim)
+      const uint32_t v = threadIdx.x < p.b1 ? cnt[threadIdx.x] : 0;
+      uint32_t tot;
+      const uint32_t ex = block_excl_scan(v, tmp, tot);
+      if (threadIdx.x < p.b1) tstart[threadIdx.x] = ex;
+      if (threadIdx.x == 0) tstart[p.b1] = tot;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < PART_PER_THREAD; k++) {
+      if (where[k] != 0xffffffffu) {
+        const uint32_t hi = where[k] >> 16, pos = tstart[hi] + (where[k] & 0xffffu);
+        stage[pos] = ent[k];
+        sbin[pos] = (uint16_t)hi;
+      }
+    }
+    __syncthreads();
+    const uint32_t total = tstart[p.b1];
+    for (uint32_t j = threadIdx.x; j < total; j += PART_THREADS) {
+      const uint32_t hi = sbin[j];
+      out[offs[hi] + (j - tstart[hi])] = stage[j];
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Generic pass over the segments of the previous level: RB more bits (the TOP rb of the `rem` bits still in the high word).
+
+// sub-job j -> (segment, entry range)
+__device__ __forceinline__ bool subjob_range(const PartSeg* __restrict__ segs, const uint32_t* __restrict__ subjob_first, uint32_t nsegs,
+                                             uint32_t j, uint32_t& seg, uint32_t& beg, uint32_t& end) {
+  if (j >= subjob_first[nsegs]) return false;
+  uint32_t lo = 0, hi = nsegs;   // last seg with subjob_first[seg] <= j (segments without sub-jobs share their successor's value)
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (subjob_first[mid] <= j) lo = mid; else hi = mid;
+  }
+  // skip empty segments that start at the same sub-job index
+  while (lo + 1 < nsegs && subjob_first[lo + 1] <= j) lo++;
+  seg = lo;
+  const PartSeg s = segs[seg];
+  const uint32_t k = j - subjob_first[seg];
+  beg = s.start + k * PART_SUBJOB;
+  end = min(s.start + s.len, beg + PART_SUBJOB);
+  return beg < end;
+}
+
+// histogram row of sub-job j: counts[j][2^rb]
+__global__ void __launch_bounds__(1024) k_pass_hist(const uint2* __restrict__ in, const PartSeg* __restrict__ segs,
+                                                    const uint32_t* __restrict__ subjob_first, PassPlan pp, uint32_t* __restrict__ counts) {
+  __shared__ uint32_t hist[1 << PART_MAX_RB];
+  const uint32_t nb = 1u << pp.rb, shift = pp.rem - pp.rb;
+  uint32_t seg, beg, end;
+  const bool live = subjob_range(segs, subjob_first, pp.nsegs, blockIdx.x, seg, beg, end);
+  if (!live) return;
+  for (uint32_t b = threadIdx.x; b < nb; b += 1024) hist[b] = 0;
+  __syncthreads();
+  for (uint32_t e = beg + threadIdx.x; e < end; e += 1024) atomicAdd(&hist[(in[e].y >> shift) & (nb - 1)], 1u);
+  __syncthreads();
+  uint32_t* row = counts + (size_t)blockIdx.x * nb;
+  for (uint32_t b = threadIdx.x; b < nb; b += 1024) row[b] = hist[b];
+}
+
+// One block per segment: turns the count rows of its sub-jobs into positions (in place) and emits the sub-segments.
+// The output range of a segment is its input range (the partition is in place segment by segment, between two buffers).
+__global__ void __launch_bounds__(1024) k_pass_scan(const PartSeg* __restrict__ segs, const uint32_t* __restrict__ subjob_first, PassPlan pp,
+                                                    uint32_t* __restrict__ counts, PartSeg* __restrict__ out_segs) {
+  __shared__ uint32_t tmp[32];
+  const uint32_t s = blockIdx.x, nb = 1u << pp.rb, b = threadIdx.x;
+  const PartSeg sg = segs[s];
+  const uint32_t j0 = subjob_first[s], j1 = subjob_first[s + 1];
+  uint32_t tot_b = 0;
+  if (b < nb)
+    for (uint32_t j = j0; j < j1; j++) tot_b += counts[(size_t)j * nb + b];
+  uint32_t tot;
+  const uint32_t before = block_excl_scan(tot_b, tmp, tot);
+  if (b < nb) {
+    uint32_t run = sg.start + before;
+    if (out_segs) out_segs[(size_t)s * nb + b] = PartSeg{run, tot_b, sg.key_base + (b << (pp.rem - pp.rb)), 0};
+    for (uint32_t j = j0; j < j1; j++) {
+      const size_t at = (size_t)j * nb + b;
+      const uint32_t v = counts[at];
+      counts[at] = run;
+      run += v;
+    }
+  }
+}
+
+// sub-job prefix for the NEXT pass over the sub-segments this pass produced (one block; nsegs_out <= a few million)
+__global__ void __launch_bounds__(1024) k_pass_subjobs(const PartSeg* __restrict__ segs, uint32_t nsegs, uint32_t* __restrict__ subjob_first,
+                                                       uint32_t* __restrict__ totals) {
+  __shared__ uint32_t tmp[32];
+  __shared__ uint32_t carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (uint32_t s0 = 0; s0 < nsegs; s0 += 1024) {
+    const uint32_t s = s0 + threadIdx.x;
+    const uint32_t nsj = s < nsegs ? (segs[s].len + PART_SUBJOB - 1) / PART_SUBJOB : 0;
+    uint32_t tot;
+    const uint32_t before = block_excl_scan(nsj, tmp, tot);
+    const uint32_t base = carry;
+    if (s < nsegs) subjob_first[s] = base + before;
+    __syncthreads();
+    if (threadIdx.x == 0) carry = base + tot;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    subjob_first[nsegs] = carry;
+    totals[1] = carry;
+  }
+}
+
+// Scatter of one sub-job: LDS multisplit tile by tile, cursors of the sub-job in LDS, runs written contiguously.
+__global__ void __launch_bounds__(1024) k_pass_scatter(const uint2* __restrict__ in, const PartSeg* __restrict__ segs,
+                                                       const uint32_t* __restrict__ subjob_first, PassPlan pp,
+                                                       const uint32_t* __restrict__ positions, uint2* __restrict__ out) {
+  __shared__ uint2 stage[PART_PTILE];
+  __shared__ uint16_t sbin[PART_PTILE];
+  __shared__ uint32_t cur[1 << PART_MAX_RB], cnt[1 << PART_MAX_RB], tstart[(1 << PART_MAX_RB) + 1];
+  __shared__ uint32_t tmp[32];
+  const uint32_t nb = 1u << pp.rb, shift = pp.rem - pp.rb, keepmask = (1u << shift) - 1;
+  uint32_t seg, beg, end;
+  const bool live = subjob_range(segs, subjob_first, pp.nsegs, blockIdx.x, seg, beg, end);
+  if (!live) return;
+  const uint32_t key_base = segs[seg].key_base;
+  const uint32_t* row = positions + (size_t)blockIdx.x * nb;
+  for (uint32_t b = threadIdx.x; b < nb; b += 1024) cur[b] = row[b];
+  constexpr int PER = PART_PTILE / 1024;
+  for (uint32_t t0 = beg; t0 < end; t0 += PART_PTILE) {
+    for (uint32_t b = threadIdx.x; b < nb; b += 1024) cnt[b] = 0;
+    __syncthreads();
+    uint2 ent[PER];
+    uint32_t where[PER];
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+      const uint32_t e = t0 + threadIdx.x + k * 1024;
+      where[k] = 0xffffffffu;
+      if (e < end) {
+        ent[k] = in[e];
+        const uint32_t bin = (ent[k].y >> shift) & (nb - 1);
+        const uint32_t rank = atomicAdd(&cnt[bin], 1u);
+        where[k] = (bin << 16) | rank;
+        // high word: the bits still unresolved, or -- after the last pass -- the full key
+        ent[k].y = pp.last ? key_base + bin : (ent[k].y & keepmask);
+      }
+    }
+    __syncthreads();
+    {
+      const uint32_t v = threadIdx.x < nb ? cnt[threadIdx.x] : 0;
+      uint32_t tot;
+      const uint32_t ex = block_excl_scan(v, tmp, tot);
+      if (threadIdx.x < nb) tstart[threadIdx.x] = ex;
+      if (threadIdx.x == 0) tstart[nb] = tot;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+      if (where[k] != 0xffffffffu) {
+        const uint32_t bin = where[k] >> 16, pos = tstart[bin] + (where[k] & 0xffffu);
+        stage[pos] = ent[k];
+        sbin[pos] = (uint16_t)bin;
+      }
+    }
+    __syncthreads();
+    const uint32_t total = tstart[nb];
+    for (uint32_t j = threadIdx.x; j < total; j += 1024) {
+      const uint32_t bin = sbin[j];
+      out[cur[bin] + (j - tstart[bin])] = stage[j];
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < nb; b += 1024) cur[b] += cnt[b];
+    // (the zeroing of cnt at the top of the next tile is ordered behind this update by its own barrier)
+    __syncthreads();
+  }
+}
+
+}  // namespace msm
+
+// ---- the launch sequence -------------------------------------------------------------------------------------------------------
+namespace msm {
+
+// Enqueues the whole grouping on `st`; returns the index (0/1) of the entry buffer that holds the result.
+// `mid` (optional) is recorded after level 1 so the caller can time the two halves.
+template <class FR, bool MONT>
+inline int part_run(const uint32_t* d_scalars, const uint8_t* d_inf, const PartPlan& p, const PartBuffers& b, hipStream_t st,
+                    hipEvent_t mid, hipError_t& err) {
+  err = hipSuccess;
+  const uint64_t entries = (uint64_t)p.n * p.windows;
+  const dim3 scan_grid(part_ceil_div(p.nbins, 256), PART_SCAN_GROUPS);
+  hipLaunchKernelGGL((k_l1_hist<FR, MONT>), dim3(p.ntiles), dim3(PART_THREADS), p.nbins * 4, st, d_scalars, d_inf, p, b.matrix);
+  hipLaunchKernelGGL(k_l1_scan_a, scan_grid, dim3(256), 0, st, b.matrix, p, b.partial);
+  hipLaunchKernelGGL(k_l1_scan_b, dim3(1), dim3(1024), 0, st, b.partial, p, b.segs[0], b.subjob_first, b.totals);
+  hipLaunchKernelGGL(k_l1_scan_c, scan_grid, dim3(256), 0, st, b.matrix, p, b.partial);
+  int seg_cur = 0;
+  uint64_t nsegs = p.nbins;
+  if (p.shared) {
+    hipLaunchKernelGGL(k_l1_merge_shared, dim3(1), dim3(256), 0, st, b.segs[0], p, b.segs[1], b.subjob_first, b.totals);
+    seg_cur = 1;
+    nsegs = p.b1;
+  }
+  hipLaunchKernelGGL((k_l1_scatter<FR, MONT>), dim3(p.ntiles), dim3(PART_THREADS), 0, st, d_scalars, d_inf, p, b.matrix, b.entries[0]);
+  if (mid) (void)hipEventRecord(mid, st);
+  uint32_t rb[4];
+  const int np = part_pass_bits(p.lb, rb);
+  uint32_t rem = p.lb;
+  int cur = 0;
+  for (int i = 0; i < np; i++) {
+    PassPlan pp{};
+    pp.nsegs = (uint32_t)nsegs;
+    pp.rem = rem;
+    pp.rb = rb[i];
+    pp.last = (i == np - 1) ? 1 : 0;
+    pp.max_subjobs = part_max_subjobs(entries, nsegs);
+    PartSeg* out_segs = pp.last ? nullptr : b.segs[seg_cur ^ 1];
+    hipLaunchKernelGGL(k_pass_hist, dim3(pp.max_subjobs), dim3(1024), 0, st, b.entries[cur], b.segs[seg_cur], b.subjob_first, pp, b.counts);
+    hipLaunchKernelGGL(k_pass_scan, dim3(pp.nsegs), dim3(1024), 0, st, b.segs[seg_cur], b.subjob_first, pp, b.counts, out_segs);
+    hipLaunchKernelGGL(k_pass_scatter, dim3(pp.max_subjobs), dim3(1024), 0, st, b.entries[cur], b.segs[seg_cur], b.subjob_first, pp, b.counts,
+                       b.entries[cur ^ 1]);
+    cur ^= 1;
+    rem -= rb[i];
+    if (!pp.last) {
+      nsegs <<= rb[i];
+      seg_cur ^= 1;
+      hipLaunchKernelGGL(k_pass_subjobs, dim3(1), dim3(1024), 0, st, b.segs[seg_cur], (uint32_t)nsegs, b.subjob_first, b.totals);
+    }
+  }
+  err = hipGetLastError();
+  return cur;
+}
+
+}  // namespace msm

@@ -1,0 +1,126 @@
+// partition_plan.hpp -- geometry of the bucket grouping (partition.hpp): plain structs and host arithmetic, no kernels, so the
+// engine can size buffers and plan launches without instantiating device code.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include <algorithm>
+
+namespace msm {
+
+constexpr int PART_TILE = 8192;        // scalars per level-1 tile (8 per thread of a 1024-thread block)
+constexpr int PART_THREADS = 1024;
+constexpr int PART_PER_THREAD = PART_TILE / PART_THREADS;
+constexpr int PART_MAX_HB = 9;         // level-1 bins per window: 2^HB <= 512
+constexpr int PART_MAX_RB = 10;        // bins of one generic pass: 2^RB <= 1024
+constexpr uint32_t PART_SUBJOB = 192u << 10;   // entries per sub-job of a generic pass
+constexpr int PART_PTILE = 8192;       // entries per LDS-staged tile of a generic pass
+constexpr int PART_SCAN_GROUPS = 64;   // tile groups of the level-1 column scan
+
+struct PartSeg {          // a run of entries that share their high key bits
+  uint32_t start, len;    // position in the entry array
+  uint32_t key_base;      // key bits already resolved (full key = key_base + the bits still in the entries' high word)
+  uint32_t pad;
+};
+
+// Geometry of one grouping problem, filled by the host (part_plan in msm_engine.hip).
+struct PartPlan {
+  uint32_t n, c, windows, half;      // scalars, window bits, digit windows, 2^(c-1)
+  uint32_t shared;                   // 1: precomputed tables, all windows share one bucket set
+  uint32_t idx0, table_stride;       // base index of scalar 0, distance between table levels
+  uint32_t hb, lb;                   // bucket bits resolved by level 1 / left after it (hb + lb = c - 1)
+  uint32_t b1;                       // 2^hb
+  uint32_t nbins;                    // level-1 bins = segments after level 1: windows * b1
+  uint32_t ntiles;                   // ceil(n / PART_TILE)
+  uint32_t tiles_per_group;          // column-scan grouping
+};
+
+// Geometry of one generic pass.
+struct PassPlan {
+  uint32_t nsegs;       // segments coming in
+  uint32_t rem, rb;     // key bits still unresolved in the entries / resolved by this pass
+  uint32_t last;        // 1: write the full key into the high word (rem == rb)
+  uint32_t max_subjobs; // grid size (upper bound; the real count is in totals[1])
+};
+
+
+inline uint32_t part_ceil_div(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
+
+// `shared` = all windows feed one bucket set (precomputed tables).
+inline PartPlan part_plan(uint32_t n, uint32_t c, uint32_t windows, bool shared, uint32_t idx0, uint32_t table_stride) {
+  PartPlan p{};
+  p.n = n;
+  p.c = c;
+  p.windows = windows;
+  p.half = 1u << (c - 1);
+  p.shared = shared ? 1 : 0;
+  p.idx0 = idx0;
+  p.table_stride = table_stride;
+  const uint32_t bits = c - 1;
+  p.hb = bits < (uint32_t)PART_MAX_HB ? bits : (uint32_t)PART_MAX_HB;
+  p.lb = bits - p.hb;
+  p.b1 = 1u << p.hb;
+  p.nbins = windows * p.b1;
+  p.ntiles = part_ceil_div(n, PART_TILE);
+  if (p.ntiles == 0) p.ntiles = 1;
+  p.tiles_per_group = part_ceil_div(p.ntiles, PART_SCAN_GROUPS);
+  return p;
+}
+
+// Bits taken by each generic pass after level 1: as few passes as possible, at most PART_MAX_RB bits each, split evenly.
+// Always at least one pass (it is the pass that writes the full key into the entries), possibly over zero bits.
+inline int part_pass_bits(uint32_t lb, uint32_t (&rb)[4]) {
+  int np = (int)((lb + PART_MAX_RB - 1) / PART_MAX_RB);
+  if (np == 0) np = 1;
+  uint32_t left = lb;
+  for (int i = 0; i < np; i++) {
+    rb[i] = (left + (uint32_t)(np - i) - 1) / (uint32_t)(np - i);
+    left -= rb[i];
+  }
+  return np;
+}
+
+// Upper bound of the sub-jobs of a pass over `nsegs` segments holding `entries` entries in total.
+inline uint32_t part_max_subjobs(uint64_t entries, uint64_t nsegs) { return (uint32_t)(entries / PART_SUBJOB + nsegs + 1); }
+
+// Device scratch the grouping needs besides the two entry buffers; sizes in bytes for a plan.
+struct PartScratchSizes {
+  size_t matrix, partial, segs_a, segs_b, subjob_first, counts, totals;
+};
+inline PartScratchSizes part_scratch_sizes(const PartPlan& p) {
+  PartScratchSizes s{};
+  const uint64_t entries = (uint64_t)p.n * p.windows;
+  s.matrix = (size_t)p.ntiles * p.nbins * 4;
+  s.partial = (size_t)PART_SCAN_GROUPS * p.nbins * 4;
+  uint32_t rb[4];
+  const int np = part_pass_bits(p.lb, rb);
+  // segment counts per level: level 1 -> nbins (or b1 merged segments when shared), then x 2^rb per pass
+  uint64_t nsegs = p.shared ? p.b1 : p.nbins, max_segs = p.nbins, max_counts = 0, max_sj = 0;
+  for (int i = 0; i < np; i++) {
+    const uint64_t sj = part_max_subjobs(entries, nsegs);
+    max_counts = std::max<uint64_t>(max_counts, sj << rb[i]);
+    max_sj = std::max<uint64_t>(max_sj, nsegs + 1);
+    nsegs <<= rb[i];
+    if (i + 1 < np) max_segs = std::max<uint64_t>(max_segs, nsegs);
+  }
+  max_sj = std::max<uint64_t>(max_sj, max_segs + 1);
+  s.segs_a = s.segs_b = (size_t)max_segs * sizeof(PartSeg);
+  s.subjob_first = (size_t)(max_sj + 1) * 4;
+  s.counts = (size_t)max_counts * 4;
+  s.totals = 64;
+  return s;
+}
+
+struct PartBuffers {
+  uint2* entries[2];         // each windows * n entries
+  uint32_t* matrix;
+  uint32_t* partial;
+  PartSeg* segs[2];
+  uint32_t* subjob_first;
+  uint32_t* counts;
+  uint32_t* totals;          // [0] = real entries (read by the accumulation), [1] = sub-jobs of the pass in flight
+};
+
+
+}  // namespace msm

@@ -25,7 +25,7 @@ void* MSMAllocContext(int32_t maxPoints, int32_t maxBatches) {
   (void)maxBatches;
   yrrid_ctx* y = (yrrid_ctx*)calloc(1, sizeof *y);
   if (!y) return NULL;
-  take(y, mi355_msm_create(&y->ctx, MI355_BLS12_377_G1, -1));
+  take(y, mi355_msm_create_env(&y->ctx, MI355_BLS12_377_G1));
   return y;
 }
 

@@ -22,7 +22,7 @@ static RustError shim_error(const char* msg) {
 RustError mult_pippenger_init(RustContext* context, const void* points, size_t npoints, size_t ffi_affine_sz) {
   if (!context) return shim_error("mult_pippenger_init: null context");
   mi355_msm_ctx* ctx = NULL;
-  RustError e = mi355_msm_create(&ctx, SHIM_CURVE, -1);
+  RustError e = mi355_msm_create_env(&ctx, SHIM_CURVE);
   if (e.code) return e;
   e = mi355_msm_set_bases(ctx, points, npoints, ffi_affine_sz);
   if (e.code) {

@@ -1,4 +1,4 @@
-// te.cuh -- twisted-Edwards image of BLS12-377 G1 in extended coordinates, over fp28.
+// te.hpp -- twisted-Edwards image of BLS12-377 G1 in extended coordinates, over fp28.
 //
 // y^2 = x^3 + 1 over the BLS12-377 base field has the rational 2-torsion point (-1, 0) and 3 is a square, so the curve is
 // birationally equivalent to  -X^2 + Y^2 = 1 + d X^2 Y^2  (the "curve isogeny" trick of the Trapdoor-Tech entry,
@@ -18,7 +18,7 @@
 // Extended points reuse XyzzT<Fe>: x = X, y = Y, zz = Z, zzz = T with X Y = Z T; all four are class M (strictly normalized
 // limbs, value < 1.5p).  Base records hold (X, Y, 2 d X Y), canonical.
 #pragma once
-#include "curve.cuh"
+#include "curve.hpp"
 
 namespace msm {
 
@@ -66,12 +66,13 @@ MSM_HD void te_madd(Xyzz& acc, const TeAffine& b, bool negate, const Modulus<F>&
   Fe ymx, ypx, t, td, ntd;
   fe_sub(ymx, b.y, b.x, F::BIAS2_28);   // (p, 3p), limbs < 2^28 + 2^29
   fe_add(ypx, b.y, b.x);                // < 2p,    limbs < 2^29
+  const LaneMask neg = lane_mask(negate);
   t = ymx;
-  fe_cmov(ymx, ypx, negate);
-  fe_cmov(ypx, t, negate);
+  fe_cmov(ymx, ypx, neg);
+  fe_cmov(ypx, t, neg);
   fe_neg(ntd, b.td, F::BIAS2_28);       // (p, 2p], limbs < 2^29
   td = b.td;
-  fe_cmov(td, ntd, negate);
+  fe_cmov(td, ntd, neg);
   Fe a1, b1, A, B, C, D;
   fe_sub(a1, acc.y, acc.x, F::BIAS2_28);   // (0, 4p), limbs < 2^28 + 2^29
   fe_add(b1, acc.y, acc.x);                // < 4p,    limbs < 2^29

@@ -80,6 +80,9 @@ def load_library() -> ctypes.CDLL:
     vp, sz, ci = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
     sigs = {
         "mi355_msm_create": [ctypes.POINTER(vp), ci, ci],
+        "mi355_msm_create_sharded": [ctypes.POINTER(vp), ci, ctypes.POINTER(ci), ci],
+        "mi355_msm_create_env": [ctypes.POINTER(vp), ci],
+        "mi355_msm_shard_bounds": [sz, ci, ci, ctypes.POINTER(sz), ctypes.POINTER(sz)],
         "mi355_msm_destroy": [vp],
         "mi355_msm_set_bases": [vp, vp, sz, sz],
         "mi355_msm_set_bases_device": [vp, vp, sz, sz],
@@ -177,12 +180,39 @@ def _flat_bytes(obj):
 class MultiScalarMultContext:
     """``#[repr(C)] struct MultiScalarMultContext { context: *mut c_void }`` (P1A 6block/src/lib.rs:18-21)."""
 
-    def __init__(self, curve="bls12_377_g1", device: Optional[int] = None):
+    def __init__(self, curve="bls12_377_g1", device: Optional[int] = None, devices: Optional[Sequence[int]] = None):
+        """``device``: one GPU (None = the current HIP device).  ``devices``: a SHARDED context over those GPUs, one slice of the
+        bases and of every scalar batch per entry (an id may repeat: logical shards on one GPU); same methods, same results."""
         self.curve = _curve_id(curve)
         self._lib = load_library()
         self.context = ctypes.c_void_p()
-        _check(self._lib.mi355_msm_create(ctypes.byref(self.context), self.curve, -1 if device is None else device))
+        self.devices = None if devices is None else [int(d) for d in devices]
+        if self.devices is not None:
+            arr = (ctypes.c_int * len(self.devices))(*self.devices)
+            _check(self._lib.mi355_msm_create_sharded(ctypes.byref(self.context), self.curve, arr, len(self.devices)))
+            self.device = None
+        else:
+            _check(self._lib.mi355_msm_create(ctypes.byref(self.context), self.curve, -1 if device is None else device))
+            self.device = self.query("device")
         self.npoints = 0
+
+    def _check_device(self, b: "_Buf", what: str) -> None:
+        # a pointer from another GPU would be dereferenced after hipSetDevice(ctx.device): fail with a clear message instead
+        if b.is_device and self.device is not None and b.device_index != self.device:
+            raise MsmError(-1, f"{what} live on cuda:{b.device_index} but this context is bound to device {self.device}")
+
+    @classmethod
+    def from_env(cls, curve="bls12_377_g1") -> "MultiScalarMultContext":
+        """What the harness shims do: honour MI355_MSM_DEVICES ("0,1,2,3", "0-7", "all"; unset = the current device)."""
+        self = cls.__new__(cls)
+        self.curve = _curve_id(curve)
+        self._lib = load_library()
+        self.context = ctypes.c_void_p()
+        _check(self._lib.mi355_msm_create_env(ctypes.byref(self.context), self.curve))
+        self.npoints = 0
+        self.devices = None
+        self.device = None if self.query("shards") else self.query("device")
+        return self
 
     def set_bases(self, points, stride: Optional[int] = None) -> None:
         stride = affine_stride(self.curve) if stride is None else stride
@@ -190,12 +220,14 @@ class MultiScalarMultContext:
         if b.nbytes % stride:
             raise ValueError(f"points image of {b.nbytes} bytes is not a multiple of the {stride}-byte affine stride")
         n = b.nbytes // stride
+        self._check_device(b, "bases")
         fn = self._lib.mi355_msm_set_bases_device if b.is_device else self._lib.mi355_msm_set_bases
         _check(fn(self.context, b.ptr, n, stride))
         self.npoints = n
 
     def run(self, scalars, npoints: Optional[int] = None) -> List[bytes]:
         b = _Buf(scalars)
+        self._check_device(b, "scalars")
         n = self.npoints if npoints is None else npoints
         if b.nbytes % SCALAR_BYTES:
             raise ValueError("scalars image is not a multiple of 32 bytes")
@@ -219,18 +251,19 @@ class MultiScalarMultContext:
         _check(self._lib.mi355_msm_set_option(self.context, key.encode(), int(value)))
 
     def query(self, key: str) -> int:
-        """Context state: "twisted_edwards", "twisted_edwards_fallbacks", "bases", "table_levels", "table_window_bits", "base_bytes"."""
+        """Context state: "twisted_edwards", "twisted_edwards_fallbacks", "twisted_edwards_demotions", "oom_backoffs", "chunk_cap",
+        "device", "shards", "rccl_exchanges", "bases", "table_levels", "table_window_bits", "base_bytes"."""
         v = ctypes.c_uint64(0)
         _check(self._lib.mi355_msm_query(self.context, key.encode(), ctypes.byref(v)))
         return int(v.value)
 
     def last_timings(self) -> dict:
         ms = (ctypes.c_float * 8)()
-        info = (ctypes.c_uint64 * 6)()
+        info = (ctypes.c_uint64 * 8)()
         _check(self._lib.mi355_msm_last_timings(self.context, ms, info))
         d = {name: float(ms[i]) for i, name in enumerate(T_NAMES)}
         d.update(window_bits=int(info[0]), windows=int(info[1]), entries=int(info[2]), lane_entries=int(info[3]),
-                 launches=int(info[4]), lanes=int(info[5]))
+                 launches=int(info[4]), lanes=int(info[5]), tables=bool(info[6]), twisted_edwards=bool(info[7]))
         return d
 
     def close(self) -> None:
@@ -245,9 +278,15 @@ class MultiScalarMultContext:
             pass
 
 
-def multi_scalar_mult_init(points, curve="bls12_377_g1", device: Optional[int] = None) -> MultiScalarMultContext:
-    """Upload (and convert) the fixed base vector once; untimed in the reference bench (benches/msm.rs:21)."""
-    ctx = MultiScalarMultContext(curve, device)
+def multi_scalar_mult_init(points, curve="bls12_377_g1", device: Optional[int] = None,
+                           devices: Optional[Sequence[int]] = None) -> MultiScalarMultContext:
+    """Upload (and convert) the fixed base vector once; untimed in the reference bench (benches/msm.rs:21).
+    ``devices`` shards the vector over several GPUs behind the same context (see MultiScalarMultContext)."""
+    if devices is None and device is None and os.environ.get("MI355_MSM_DEVICES"):
+        ctx = MultiScalarMultContext.from_env(curve)
+        ctx.set_bases(points)
+        return ctx
+    ctx = MultiScalarMultContext(curve, device, devices)
     ctx.set_bases(points)
     return ctx
 
@@ -271,8 +310,9 @@ def msm(bases, scalars, curve="bls12_377_g1") -> bytes:
     try:
         pb, sb = _Buf(bases), _Buf(scalars)
         if pb.is_device or sb.is_device:
-            ctx.set_bases(bases[: n * stride])
-            return ctx.run(scalars[: n * SCALAR_BYTES], n)[0]
+            # chop BYTES, not rows: the inputs are usually 2-D (N, 104) / (N, 32) tensors
+            ctx.set_bases(_flat_bytes(bases)[: n * stride])
+            return ctx.run(_flat_bytes(scalars)[: n * SCALAR_BYTES], n)[0]
         out = ctypes.create_string_buffer(projective_bytes(curve))
         _check(ctx._lib.mi355_msm(ctx.curve, out, pb.ptr, n, sb.ptr, stride))
         return out.raw

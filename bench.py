@@ -51,6 +51,29 @@ def uniform_scalars(n, top_limb, device, seed):
     return limbs.view(torch.uint8).reshape(n, 32)
 
 
+def kernel_source_sha16():
+    """Identity of the kernel sources this library was built from (csrc/*): PMC figures measured on another version of the
+    kernels are not quoted as if they belonged to this one."""
+    import glob
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "2022-entries_amd", "csrc", "*"))):
+        if os.path.isfile(f):
+            h.update(os.path.basename(f).encode())
+            h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def timed(fn, reps):
+    """Wall ms per call of fn() (each call returns with the result on the host, i.e. it is synchronous)."""
+    fn()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        r = fn()
+    return (time.perf_counter() - t0) / reps * 1e3, r
+
+
 def cpu_baseline(curve, cid, bases_np, scalars_np, sample, threads):
     """Time the oracle (arkworks-algorithm restatement) on `sample` pairs; returns (pairs/s, result bytes, seconds)."""
     lib = ctypes.CDLL(os.path.join(ROOT, "oracle", "liboracle.so"))
@@ -71,7 +94,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--npow", type=int, default=26, help="log2 pairs per GPU (26 = ZPrize prize1-msm canonical size)")
     ap.add_argument("--curve", default="bls12_377_g1", choices=["bls12_377_g1", "bls12_381_g1", "bls12_377_g2"])
-    ap.add_argument("--cpu-sample-pow", type=int, default=24, help="log2 pairs of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-sample-pow", type=int, default=26,
+                    help="log2 pairs of the CPU-baseline sample (0 = skip); 26 = the whole workload once, about a minute of host time")
+    ap.add_argument("--extras", type=int, default=1,
+                    help="at N = 1 also measure, in the same run, SURVEY 8(d)'s primary metric and its neighbours: scalars in HOST memory "
+                         "(1 and 4 batches, pageable and pinned), the XYZZ group law on BLS12-377, one stateless mi355_msm() call")
+    ap.add_argument("--logical-shards", type=int, default=0,
+                    help="single-process --gpus N on a box with fewer GPUs: place the N shards on the visible devices round-robin")
     ap.add_argument("--precompute", type=int, default=0, help="1 = context with precomputed 2^(c w) P tables (row f1; init untimed)")
     ap.add_argument("--also-precompute", type=int, default=1,
                     help="at N = 1 also time a context with precomputed tables (reported as a secondary object, never as `value`)")
@@ -90,9 +119,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    # --gpus N without a launcher (WORLD_SIZE unset): ONE process drives N GPUs through the sharded context of the C ABI
+    # (mi355_msm_create_sharded: per-device host threads, RCCL all-gather of the partials, host fold).  Under
+    # torch.distributed.run the same N GPUs are one process each (dist.py), which is what the driver launches.
+    c_sharded = world == 1 and args.gpus > 1
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the MSM path has no CPU fallback")
     if args.backend == "gloo":
@@ -116,7 +146,17 @@ def main():
     tile = torch.from_numpy(base_tile).to(device)
     bases = tile.repeat(n // distinct, 1).contiguous()
     scalars = uniform_scalars(n, R381_TOP if cid == 1 else R377_TOP, device, seed=1234 + rank)
-    ctx = ea.MultiScalarMultContext(args.curve, device=local_rank)
+    if c_sharded:
+        ndev = torch.cuda.device_count()
+        if ndev < args.gpus and not args.logical_shards:
+            raise SystemExit(f"--gpus {args.gpus} but {ndev} device(s) visible (use --logical-shards 1 to rehearse on fewer)")
+        devs = [g % ndev for g in range(args.gpus)]
+        ctx = ea.MultiScalarMultContext(args.curve, devices=devs)
+        # weak scaling: 2^npow pairs PER GPU; the global problem is args.gpus times as large
+        bases = bases.repeat(args.gpus, 1)
+        scalars = torch.cat([uniform_scalars(n, R381_TOP if cid == 1 else R377_TOP, device, seed=1234 + g) for g in range(args.gpus)])
+    else:
+        ctx = ea.MultiScalarMultContext(args.curve, device=local_rank)
     if args.window_bits:
         ctx.set_option("window_bits", args.window_bits)
     if args.precompute:
@@ -161,23 +201,34 @@ def main():
         elapsed = float(tmax.item())
 
     if rank == 0:
-        pairs_per_step = n * world
+        pairs_per_step = n * world * (args.gpus if c_sharded else 1)
         value = pairs_per_step * args.steps / elapsed
         kern_s = (acc_ms / max(acc_launches, 1)) * 1e-3
         pairs_per_launch = n * args.steps / max(acc_launches, 1)
         achieved = BYTES_PER_PAIR[cid] * pairs_per_launch / kern_s / 1e9
         # HBM traffic and VALU occupancy of the dominant kernel come from separate rocprofv3 --pmc passes (committed under
         # profiles/); they are only quoted for the configuration they were measured on
-        traffic, valu = None, None
-        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_k_accumulate.json")
+        # They are NOT measured by this run (counters need their own rocprofv3 pass): `traffic_from` says where the figure was
+        # measured, and it is only quoted when that pass ran on the very kernel sources this library was built from.
+        traffic, traffic_from, valu = None, None, None
+        pmc_rel = os.path.join("profiles", "r02_pmc_k_accumulate.json")
+        pmc_path = os.path.join(ROOT, pmc_rel)
         if cid == 0 and args.npow == 26 and not args.window_bits and not args.lane_entries and not args.precompute and os.path.exists(pmc_path):
             pmc = json.load(open(pmc_path))
-            traffic = pmc["traffic_bytes_raw"]
-            valu = {"busy_fraction": pmc["derived"]["valu_busy_fraction"], "effective_clock_GHz": pmc["derived"]["effective_clock_GHz"],
-                    "valu_instr_per_mixed_add": pmc["derived"]["valu_instr_per_mixed_add"], "source": "profiles/r01_pmc_k_accumulate.json"}
+            sha = kernel_source_sha16()
+            if pmc.get("kernel_source_sha16") == sha:
+                traffic = pmc["traffic_bytes_raw"]
+                traffic_from = f"{pmc_rel}: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this workload, same kernel sources ({sha})"
+                valu = {"busy_fraction": pmc["derived"]["valu_busy_fraction"], "effective_clock_GHz": pmc["derived"]["effective_clock_GHz"],
+                        "valu_instr_per_mixed_add": pmc["derived"]["valu_instr_per_mixed_add"], "from": pmc_rel}
+            else:
+                traffic_from = (f"not quoted: {pmc_rel} was measured on kernel sources {pmc.get('kernel_source_sha16')}, "
+                                f"this library is built from {sha}")
         # the integer roofline: lane-level v_mad_u64_u32 per second in the dominant kernel against the measured
         # issue peak of 1024 SIMDs x 64 lanes / 4.3 cycles at the nominal 2.4 GHz (profiles/r01_ubench_valu_*.txt)
         te_path = bool(ctx.query("twisted_edwards"))
+        # v_mad_u64_u32 per mixed addition: a property of the formulas (7 multiplications of 378; 6M + 2S + one fused dual product),
+        # pinned on the generated ISA by tests/test_isa.py
         mads_per_add = {0: 2646 if te_path else 3416, 1: 3542, 2: 11584}[cid]
         adds_per_launch = tm["entries"]          # one mixed addition per sorted entry (zero digits are a ~1e-6 fraction)
         mad_rate = mads_per_add * adds_per_launch / kern_s
@@ -186,7 +237,7 @@ def main():
             "metric": {0: "BLS12-377 G1", 1: "BLS12-381 G1", 2: "BLS12-377 G2"}[cid] + " MSM point-scalar pairs/s",
             "value": value,
             "unit": "pairs/s",
-            "n_gpus": world,
+            "n_gpus": args.gpus if c_sharded else world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
@@ -201,10 +252,13 @@ def main():
                        "pairs_per_gpu": n, "window_bits": tm["window_bits"], "windows": tm["windows"],
                        "lane_entries": tm["lane_entries"], "precompute": bool(args.precompute),
                        "group_law": "extended twisted Edwards (7M mixed add)" if ctx.query("twisted_edwards") else "XYZZ (8M+2S mixed add)",
-                       "init_s": t_init, "parallelism": f"{world} disjoint base/scalar slices + all-gather of {world} partial points"},
+                       "init_s": t_init,
+                       "parallelism": (f"one process, {args.gpus} shards behind the C ABI (mi355_msm_create_sharded), "
+                                       f"{'RCCL all-gather' if ctx.query('rccl_exchanges') else 'host fold'} of {args.gpus} partial points" if c_sharded else
+                                       f"{world} disjoint base/scalar slices + all-gather of {world} partial points")},
             "stage_ms_per_step": {k: v / args.steps for k, v in stage_ms.items()},
             "roofline": {"bound": "hbm", "kernel": "k_accumulate" if cid == 2 else "k_accumulate_coop", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_from": traffic_from,
                          "kernel_ms": kern_s * 1e3, "algorithmic_bytes_per_launch": BYTES_PER_PAIR[cid] * pairs_per_launch,
                          "valu": valu,
                          "integer": {"mads_per_mixed_add": mads_per_add, "lane_mads_per_s": mad_rate, "peak_lane_mads_per_s": mad_peak,
@@ -212,7 +266,50 @@ def main():
                                      "peak_is": "v_mad_u64_u32 issue limit at the nominal 2.4 GHz; the kernel runs power-limited near 1.9 GHz"},
                          "note": "integer-VALU-bound path (no MFMA): the binding resource is VALU issue at the power-limited clock (DESIGN.md section 5)"},
         }
-        if world == 1 and args.cpu_sample_pow > 0:
+        if world == 1 and not c_sharded and args.extras and cid != 2:
+            # SURVEY 8(d)'s PRIMARY metric is what the reference bench times: bases resident, scalars in HOST memory, 4 batches
+            # (P1A combined-top-solutions/benches/msm.rs:21,27-35).  `value` above keeps the scalars in HBM (the brief's rule);
+            # these are the PCIe-inclusive figures, measured in this same run.
+            try:
+                extras = {}
+                sc_np = scalars.cpu().numpy()                                   # pageable host memory
+                sc_pin = torch.from_numpy(sc_np).pin_memory()
+                ms1_page, r1 = timed(lambda: ctx.run(sc_np)[0], 3)
+                ms1_pin, r1p = timed(lambda: ctx.run(sc_pin)[0], 3)
+                extras["host_scalars"] = {"one_batch_ms": {"pageable": ms1_page, "pinned": ms1_pin}, "same_result_as_device_scalars": r1 == result and r1p == result}
+                sc4 = torch.cat([uniform_scalars(n, R381_TOP if cid == 1 else R377_TOP, device, seed=4000 + b) for b in range(4)])
+                sc4_np = sc4.cpu().numpy()
+                sc4_pin = torch.from_numpy(sc4_np).pin_memory()
+                ms4_dev, r4 = timed(lambda: ctx.run(sc4), 2)
+                ms4_page, r4p = timed(lambda: ctx.run(sc4_np), 2)
+                ms4_pin, r4q = timed(lambda: ctx.run(sc4_pin), 2)
+                extras["host_scalars"]["four_batches_ms"] = {"pageable": ms4_page, "pinned": ms4_pin, "device_resident": ms4_dev,
+                                                             "what": "the ZPrize workload: 4 x 2^%d scalars over one base vector, one call" % args.npow,
+                                                             "same_results": r4 == r4p == r4q}
+                del sc4, sc4_np, sc4_pin, sc_pin
+                if cid == 0:
+                    # the group law north_star names (XYZZ, 8M + 2S) on the same workload
+                    cx = ea.MultiScalarMultContext(args.curve, device=local_rank)
+                    cx.set_option("twisted_edwards", 0)
+                    cx.set_bases(tile.repeat(n // distinct, 1).contiguous())
+                    ms_x, rx = timed(lambda: cx.run(scalars)[0], args.steps)
+                    extras["xyzz_ms_per_step"] = ms_x
+                    extras["xyzz_accumulate_ms"] = cx.last_timings()["accumulate"]
+                    extras["xyzz_same_result"] = rx == result
+                    cx.close()
+                # one stateless call: host bases -> upload -> conversion (+ twisted-Edwards image) -> MSM -> teardown
+                bases_host = np.ascontiguousarray(np.tile(base_tile, (n // distinct, 1)))
+                t_s = time.perf_counter()
+                rs = ea.msm(bases_host, sc_np, args.curve)
+                extras["stateless_ms"] = (time.perf_counter() - t_s) * 1e3
+                extras["stateless_same_result"] = rs == result
+                extras["stateless_what"] = "mi355_msm(): %.1f GB of bases and %.1f GB of scalars from pageable host memory, everything included" % (
+                    bases_host.nbytes / 1e9, sc_np.nbytes / 1e9)
+                del bases_host
+                out["survey_8d_metrics"] = extras
+            except Exception as e:   # never lose the headline line to a secondary measurement
+                out["survey_8d_metrics"] = {"error": repr(e)}
+        if world == 1 and not c_sharded and args.cpu_sample_pow > 0:
             sample = min(n, 1 << args.cpu_sample_pow)
             cores = os.cpu_count() or 1
             if cid == 2:
@@ -229,7 +326,7 @@ def main():
                                    "sample": f"first 2^{sample.bit_length() - 1} pairs of the same workload, {dt:.1f} s, "
                                              f"arkworks-algorithm restatement (c={c}, one thread per window), host has {cores} cores",
                                    "gpu_matches_cpu_on_sample": gpu_res == cpu_res}
-        if world == 1 and args.also_precompute and not args.precompute and cid != 2:
+        if world == 1 and not c_sharded and args.also_precompute and not args.precompute and cid != 2:
             # the reference's own convention (init untimed, tables built there): reported next to the headline, not as it
             try:
                 ctx.close()   # give the headline context's ~40 GB back before the tables (95 + 142 GB while they are converted)

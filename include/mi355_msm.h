@@ -71,6 +71,22 @@ enum {
 RustError mi355_msm_create(mi355_msm_ctx** out, int curve, int device);
 RustError mi355_msm_destroy(mi355_msm_ctx* ctx);
 
+/* ---- one MSM over several GPUs, behind the SAME context API ----------------------------------------
+ * The reference is single-device (SPK msm/pippenger.cuh:400-416 hard-codes device 0), but its harness only ever calls
+ * init + run (P1A 6block/src/lib.rs:54-109; CMB MSM.h:72-75), so sharding has to live behind those calls.  A sharded context
+ * is an ordinary mi355_msm_ctx*: set_bases / set_bases_device / set_bases_serialized / run / run_device / set_option / query /
+ * last_timings / destroy all accept it.  Shard g of G owns the contiguous slice [g*ceil(n/G), ...) of the bases and of every
+ * scalar batch, one host thread + one device context + one stream per shard (the multi-stream orchestration of
+ * P1A matter-labs/src/lib.rs:125-201 with devices in place of streams); the G partial points per batch are exchanged by one
+ * ncclAllGather over RCCL/xGMI (single-process communicator; librccl is dlopen'ed) and folded on the host -- elliptic-curve
+ * addition is not an RCCL reduction operator.  The host fold of the shards' own outputs is the fallback (no librccl, or a
+ * device listed twice = logical shards on one GPU) and checks the exchanged copy.  Option "combine": 0 auto, 1 host fold only,
+ * 2 require RCCL.  Queries: "shards", "rccl_exchanges"; counters of the single-device queries add up over the shards. */
+RustError mi355_msm_create_sharded(mi355_msm_ctx** out, int curve, const int* devices, int ndevices);
+/* What the harness shims call: MI355_MSM_DEVICES = "0,1,2,3" | "0-7" | "all" selects a sharded context over those devices,
+ * one entry (or unset) an ordinary one.  mi355_msm() (stateless) goes through here as well. */
+RustError mi355_msm_create_env(mi355_msm_ctx** out, int curve);
+
 /* Bases in HOST memory (arkworks Affine images, `stride` bytes apart).  Copies; caller keeps ownership. */
 RustError mi355_msm_set_bases(mi355_msm_ctx* ctx, const void* affine, size_t npoints, size_t stride);
 /* Same, bases already resident in DEVICE memory (e.g. a torch uint8 tensor's data_ptr). */
@@ -114,12 +130,16 @@ RustError mi355_msm_set_option(mi355_msm_ctx* ctx, const char* key, long value);
  * kernels check every addition for a vanishing denominator (possible only for inputs outside the prime-order subgroup) and
  * the run is then repeated on the short-Weierstrass path.  Costs 192 B per base (per table level) of HBM on top. */
 /* State of a context: "twisted_edwards" (1 = the current bases run on the twisted-Edwards path), "twisted_edwards_fallbacks"
- * (runs repeated on the XYZZ path so far), "bases", "table_levels", "table_window_bits", "base_bytes" (device bytes held
- * for the bases). */
+ * (chunks repeated on the XYZZ path so far), "twisted_edwards_demotions" (two fallbacks in a row demote the base set to XYZZ
+ * until the next set_bases), "oom_backoffs" (chunks restarted at half size after a device allocation failed), "chunk_cap",
+ * "device", "bases", "table_levels", "table_window_bits", "base_bytes" (device bytes held for the bases). */
 RustError mi355_msm_query(mi355_msm_ctx* ctx, const char* key, uint64_t* value);
 /* Per-stage device time (ms, HIP events on the launch stream) of the most recent run, summed over its chunks
- * and batches; ms must hold MI355_T_COUNT floats.  info: [0]=window bits, [1]=windows, [2]=sorted entries of the
- * last chunk, [3]=entries per lane, [4]=accumulate launches, [5]=lanes of the last launch. */
+ * and batches (MI355_T_HOST_FOLD: host wall time of the final normalisation); ms must hold MI355_T_COUNT floats.
+ * info (8 words): [0]=window bits, [1]=windows, [2]=sorted entries of the last chunk, [3]=entries per lane, [4]=accumulate
+ * launches, [5]=lanes of the last launch, [6]=1 when precomputed tables were used, [7]=1 on the twisted-Edwards path.
+ * Chunks are sized to the device memory that is free (the reference plans its allocations first, ML msm.cu:453-466), and a
+ * chunk whose allocation fails all the same is retried at half the size. */
 RustError mi355_msm_last_timings(mi355_msm_ctx* ctx, float* ms, uint64_t* info);
 
 /* ---- stateless calls ---------------------------------------------------------------------------
@@ -144,6 +164,11 @@ RustError mi355_msm_generate_points(int curve, uint64_t seed, size_t distinct, s
  * fragment-merge launches, bucket-reduce launches, sort key bits, bytes of per-run device work buffers.
  * `options` may be NULL or {window_bits, lane_entries, seg_entries} (0 = automatic). */
 RustError mi355_msm_plan(int curve, size_t npoints, int precompute, const long* options, uint64_t* out);
+
+/* The slice [*lo, *hi) of range(npoints) that shard `shard` of `nshards` owns in a sharded context (and in dist.py's
+ * one-process-per-GPU path): ceil(npoints / nshards) consecutive pairs per shard, the last ones possibly shorter or empty.
+ * Pure host arithmetic. */
+RustError mi355_msm_shard_bounds(size_t npoints, int nshards, int shard, size_t* lo, size_t* hi);
 
 /* Library/ABI version and the gfx target the kernels were built for ("gfx950"). */
 const char* mi355_msm_version(void);

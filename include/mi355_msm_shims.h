@@ -9,7 +9,8 @@
  *   libmi355msm_zprize_{377,381}.so   2022-entries_amd/csrc/shims/zprize_harness.c
  *   libmi355msm_yrrid_377.so          2022-entries_amd/csrc/shims/yrrid_context.c
  *
- * All of them link libmi355msm.so; none contains arithmetic.
+ * All of them link libmi355msm.so; none contains arithmetic.  The context-creating shims go through mi355_msm_create_env(), so
+ * MI355_MSM_DEVICES=0,1,...,7 (or "all") turns an unchanged single-GPU harness into a sharded run over those MI355X.
  */
 #ifndef MI355_MSM_SHIMS_H
 #define MI355_MSM_SHIMS_H

@@ -249,7 +249,12 @@ class Curve:
         top bits (infinity = 0x40; P1B nickray driver/algebra/serialize/src/flags.rs:107-134)."""
         cb = self.coord_bytes
         if P is None:
-            return bytes(2 * cb - 1) + b"\x40"
+            # GroupAffine::zero() = (0, 1, infinity = true) in the 0.3-era tree the harness is built on: x = 0, y = 1 (normal
+            # form; Fq2: y.c0 = 1), flag ORed into the last byte (P1B nickray .../short_weierstrass_jacobian.rs:154-156, 827-835)
+            rec = bytearray(2 * cb)
+            rec[cb] = 1
+            rec[-1] |= 0x40
+            return bytes(rec)
         def enc(v):
             if self.ext == 1:
                 return v.to_bytes(48, "little")

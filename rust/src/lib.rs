@@ -1,0 +1,222 @@
+//! Operator API of the prize1-msm harness over the MI355X engine.
+//!
+//! Same items, argument meaning and panics as the reference's Rust layer
+//! (P1A 6block/src/lib.rs:18-21, 54-109; identical in P1A yrrid/src/lib.rs:17-20, 38-90):
+//!
+//! * `#[repr(C)] struct MultiScalarMultContext { context: *mut c_void }`
+//! * `multi_scalar_mult_init(points) -> MultiScalarMultContext`   (bases uploaded and converted once; untimed)
+//! * `multi_scalar_mult(&mut ctx, points, scalars) -> Vec<G::Projective>` with `batch_size = scalars.len() / points.len()`
+//!
+//! plus the arkworks trait shape (`msm`, `msm_checked`, `msm_bigint`;
+//! ARK ec/src/msm/variable_base/mod.rs:44-65) as free functions in [`variable_base`], and the engine's own context API
+//! in [`sys`] for callers that want options (precomputed tables, sharding over several GPUs, timings).
+//!
+//! Setting `MI355_MSM_DEVICES=0,1,...,7` (or `all`) makes the context created by `multi_scalar_mult_init` a SHARDED one:
+//! the bases and every scalar batch are split into contiguous slices, one per MI355X, and the partial points are
+//! all-gathered over RCCL/xGMI and folded -- no change on the Rust side.
+
+use std::os::raw::{c_char, c_int, c_long, c_void};
+
+use ark_ec::AffineCurve;
+use ark_ff::PrimeField;
+use ark_std::Zero;
+
+#[cfg(not(feature = "bls12_381"))]
+use ark_bls12_377::{Fr, G1Affine};
+#[cfg(feature = "bls12_381")]
+use ark_bls12_381::{Fr, G1Affine};
+
+pub mod util;
+
+/// `struct RustError { int code; char *message; }`, returned BY VALUE; `message` is malloc'd by the library and freed here
+/// (the convention of SPK util/rusterror.h:15-27 and SPK rust/src/lib.rs:17-25).  The library always supplies a message:
+/// ROCm has no `cudaGetErrorString` for the sppark macro to fall back on.
+#[repr(C)]
+pub struct Error {
+    pub code: c_int,
+    message: *mut c_char,
+}
+
+impl Drop for Error {
+    fn drop(&mut self) {
+        extern "C" {
+            fn free(str: *mut c_char);
+        }
+        if !self.message.is_null() {
+            unsafe { free(self.message) };
+            self.message = std::ptr::null_mut();
+        }
+    }
+}
+
+impl From<&Error> for String {
+    fn from(status: &Error) -> Self {
+        if status.message.is_null() {
+            format!("mi355-msm error {}", status.code)
+        } else {
+            let c_str = unsafe { std::ffi::CStr::from_ptr(status.message) };
+            String::from(c_str.to_str().unwrap_or("unintelligible"))
+        }
+    }
+}
+
+impl From<Error> for String {
+    fn from(status: Error) -> Self {
+        String::from(&status)
+    }
+}
+
+#[repr(C)]
+pub struct MultiScalarMultContext {
+    context: *mut c_void,
+}
+
+// The harness-named entry points: libmi355msm_zprize_{377,381}.so (2022-entries_amd/csrc/shims/zprize_harness.c),
+// signatures of P1A 6block/cuda/pippenger_inf.cu:50-53, 87-92.
+extern "C" {
+    fn mult_pippenger_init(
+        context: *mut MultiScalarMultContext,
+        points_with_infinity: *const G1Affine,
+        npoints: usize,
+        ffi_affine_sz: usize,
+    ) -> Error;
+
+    fn mult_pippenger_inf(
+        context: *mut MultiScalarMultContext,
+        out: *mut u64,
+        points_with_infinity: *const G1Affine,
+        npoints: usize,
+        batch_size: usize,
+        scalars: *const Fr,
+        ffi_affine_sz: usize,
+    ) -> Error;
+}
+
+/// The engine's canonical C ABI (include/mi355_msm.h), for callers that want more than the harness API.
+pub mod sys {
+    use super::{c_char, c_int, c_long, c_void, Error};
+
+    pub const MI355_BLS12_377_G1: c_int = 0;
+    pub const MI355_BLS12_381_G1: c_int = 1;
+    pub const MI355_BLS12_377_G2: c_int = 2;
+
+    extern "C" {
+        pub fn mi355_msm_create(out: *mut *mut c_void, curve: c_int, device: c_int) -> Error;
+        pub fn mi355_msm_create_sharded(out: *mut *mut c_void, curve: c_int, devices: *const c_int, ndevices: c_int) -> Error;
+        pub fn mi355_msm_create_env(out: *mut *mut c_void, curve: c_int) -> Error;
+        pub fn mi355_msm_destroy(ctx: *mut c_void) -> Error;
+        pub fn mi355_msm_set_bases(ctx: *mut c_void, affine: *const c_void, npoints: usize, stride: usize) -> Error;
+        pub fn mi355_msm_set_bases_serialized(ctx: *mut c_void, records: *const c_void, npoints: usize) -> Error;
+        pub fn mi355_msm_run(ctx: *mut c_void, out_projective: *mut c_void, scalars: *const c_void, npoints: usize, batches: usize) -> Error;
+        pub fn mi355_msm_set_option(ctx: *mut c_void, key: *const c_char, value: c_long) -> Error;
+        pub fn mi355_msm_query(ctx: *mut c_void, key: *const c_char, value: *mut u64) -> Error;
+        pub fn mi355_msm_last_timings(ctx: *mut c_void, ms: *mut f32, info: *mut u64) -> Error;
+        pub fn mi355_msm(curve: c_int, out_projective: *mut c_void, affine: *const c_void, npoints: usize, scalars: *const c_void, ffi_affine_sz: usize) -> Error;
+        pub fn mi355_msm_fold(curve: c_int, out_projective: *mut c_void, projective: *const c_void, count: usize) -> Error;
+        pub fn mi355_msm_point_to_serialized(curve: c_int, projective: *const c_void, out_record: *mut c_void) -> Error;
+    }
+}
+
+/// Uploads (and converts) the fixed base vector; the reference bench leaves this outside the timed region
+/// (P1A combined-top-solutions/benches/msm.rs:21).
+pub fn multi_scalar_mult_init<G: AffineCurve>(points: &[G]) -> MultiScalarMultContext {
+    let mut ret = MultiScalarMultContext { context: std::ptr::null_mut() };
+    let err = unsafe {
+        mult_pippenger_init(&mut ret, points as *const _ as *const G1Affine, points.len(), std::mem::size_of::<G1Affine>())
+    };
+    if err.code != 0 {
+        panic!("{}", String::from(err));
+    }
+    ret
+}
+
+/// One projective result per batch of `points.len()` scalars.  Scalars are `BigInteger256` images (plain integers).
+pub fn multi_scalar_mult<G: AffineCurve>(
+    context: &mut MultiScalarMultContext,
+    points: &[G],
+    scalars: &[<G::ScalarField as PrimeField>::BigInt],
+) -> Vec<G::Projective> {
+    let npoints = points.len();
+    if npoints == 0 || scalars.len() % npoints != 0 {
+        panic!("length mismatch")
+    }
+    let batch_size = scalars.len() / npoints;
+    let mut ret = vec![G::Projective::zero(); batch_size];
+    let err = unsafe {
+        mult_pippenger_inf(
+            context,
+            ret.as_mut_ptr() as *mut u64,
+            points as *const _ as *const G1Affine,
+            npoints,
+            batch_size,
+            scalars as *const _ as *const Fr,
+            std::mem::size_of::<G1Affine>(),
+        )
+    };
+    if err.code != 0 {
+        panic!("{}", String::from(err));
+    }
+    ret
+}
+
+/// The arkworks trait surface as free functions (a foreign trait cannot be implemented for a foreign type from here; a fork
+/// of ark-ec would put these bodies into `impl VariableBaseMSM for G1Projective`).
+pub mod variable_base {
+    use super::sys;
+    use super::{Fr, G1Affine};
+    use ark_ec::AffineCurve;
+    use ark_ff::PrimeField;
+    use ark_std::Zero;
+    use std::os::raw::{c_char, c_int, c_void};
+
+    type G1Projective = <G1Affine as AffineCurve>::Projective;
+
+    #[cfg(not(feature = "bls12_381"))]
+    const CURVE: c_int = sys::MI355_BLS12_377_G1;
+    #[cfg(feature = "bls12_381")]
+    const CURVE: c_int = sys::MI355_BLS12_381_G1;
+
+    fn run(bases: &[G1Affine], scalars: *const c_void, n: usize, montgomery: bool) -> G1Projective {
+        let mut out = G1Projective::zero();
+        unsafe {
+            let mut ctx: *mut c_void = std::ptr::null_mut();
+            let mut err = sys::mi355_msm_create_env(&mut ctx, CURVE);
+            if err.code == 0 && montgomery {
+                // `Fr` holds a * 2^256 mod r; the device converts, as `into_bigint` does on the CPU
+                err = sys::mi355_msm_set_option(ctx, b"scalars_montgomery\0".as_ptr() as *const c_char, 1);
+            }
+            if err.code == 0 {
+                err = sys::mi355_msm_set_bases(ctx, bases.as_ptr() as *const c_void, n, std::mem::size_of::<G1Affine>());
+            }
+            if err.code == 0 {
+                err = sys::mi355_msm_run(ctx, &mut out as *mut _ as *mut c_void, scalars, n, 1);
+            }
+            if !ctx.is_null() {
+                let _ = sys::mi355_msm_destroy(ctx);
+            }
+            if err.code != 0 {
+                panic!("{}", String::from(err));
+            }
+        }
+        out
+    }
+
+    /// `VariableBaseMSM::msm_bigint`: chops to the shorter slice (ARK ec/src/msm/variable_base/mod.rs:68-76).
+    pub fn msm_bigint(bases: &[G1Affine], bigints: &[<Fr as PrimeField>::BigInt]) -> G1Projective {
+        let n = bases.len().min(bigints.len());
+        run(bases, bigints.as_ptr() as *const c_void, n, false)
+    }
+
+    /// `VariableBaseMSM::msm` on field elements (ARK ec/src/msm/variable_base/mod.rs:48-53).
+    pub fn msm(bases: &[G1Affine], scalars: &[Fr]) -> G1Projective {
+        let n = bases.len().min(scalars.len());
+        run(bases, scalars.as_ptr() as *const c_void, n, true)
+    }
+
+    /// `VariableBaseMSM::msm_checked` (ARK ec/src/msm/variable_base/mod.rs:61-65).
+    pub fn msm_checked(bases: &[G1Affine], scalars: &[Fr]) -> Result<G1Projective, usize> {
+        (bases.len() == scalars.len())
+            .then(|| msm(bases, scalars))
+            .ok_or(usize::min(bases.len(), scalars.len()))
+    }
+}

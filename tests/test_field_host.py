@@ -1,4 +1,4 @@
-"""CPU: the kernels' own arithmetic (fp28.cuh / curve.cuh, radix-2^28 lazy reduction) compiled for the host with the
+"""CPU: the kernels' own arithmetic (fp28.hpp / curve.hpp, radix-2^28 lazy reduction) compiled for the host with the
 limb-bound checker armed, against the Python model.  This is where the lazy-reduction bounds are proven not to overflow."""
 import ctypes
 import os

@@ -289,6 +289,23 @@ def test_g2_random_vs_oracle(ea, oracle, torch_cuda, npow):
     ctx.close()
 
 
+def test_g2_reference_generator_has_order_r_on_the_gpu(ea, golden_constants, torch_cuda):
+    """The reference's G2 generator literal (tests/golden/constants.json, from ARKC bls12_377/src/curves/g2.rs:61-78) through the
+    HIP path: r * G2 = O, (r - 1) * G2 = -G2, and 2^15 copies of G2 with scalars summing to r also vanish."""
+    c = m.BLS12_377_G2
+    k = golden_constants["bls12_377_g2"]
+    G = c.generator()
+    assert (G[0].c0, G[0].c1, G[1].c0, G[1].c1) == tuple(int(k[n]) for n in ("GX0", "GX1", "GY0", "GY1")) and c.on_curve(G)
+    base = c.encode_affine_array([G])
+    assert ea.msm(base, m.encode_scalars([c.r]), c.name) == c.encode_projective_normalized(None)
+    assert ea.msm(base, m.encode_scalars([c.r - 1]), c.name) == c.encode_projective_normalized(c.neg(G))
+    n = 1 << 15
+    rng = random.Random(15)
+    sc = [rng.randrange(c.r) for _ in range(n - 1)]
+    sc.append((-sum(sc)) % c.r)
+    assert ea.msm(base * n, m.encode_scalars(sc), c.name) == c.encode_projective_normalized(None)
+
+
 def test_g2_edge_cases_and_stateless(ea, oracle, torch_cuda):
     c = m.BLS12_377_G2
     rng = random.Random(77)

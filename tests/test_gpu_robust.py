@@ -1,0 +1,105 @@
+"""GPU: the engine's back-off paths, forced.  (1) chunks are sized to the device memory that is free (the reference plans its
+allocations before it runs, ML msm.cu:453-466): the "mem_limit" test hook shrinks the budget; (2) an allocation that fails all
+the same halves the chunk and retries ("inject_alloc_failures"); (3) a base set that trips the incomplete twisted-Edwards
+law twice in a row is demoted to XYZZ instead of paying for both paths on every call.  Results never change."""
+import random
+
+import numpy as np
+import pytest
+
+import pymodel as m
+import te_model as te
+from conftest import oracle_msm_np
+
+pytestmark = pytest.mark.gpu
+
+C = m.BLS12_377_G1
+
+
+def _scalars(n, seed):
+    rng = np.random.default_rng(seed)
+    limbs = rng.integers(0, 1 << 64, size=(n, 4), dtype=np.uint64)
+    limbs[:, 3] %= np.uint64(0x12ab655e9a2ca556)
+    return limbs.view(np.uint8).reshape(n, 32)
+
+
+@pytest.mark.parametrize("curve,cid", [("bls12_377_g1", 0), ("bls12_381_g1", 1)])
+def test_chunks_shrink_to_the_memory_budget(ea, oracle, curve, cid):
+    n = 1 << 17
+    bases = ea.generate_points(n, distinct=1 << 10, seed=6, curve=curve)
+    sc = _scalars(n, 2)
+    sc[:, 31] &= 0x0F
+    exp = oracle_msm_np(oracle, cid, bases, sc, n)
+    ctx = ea.multi_scalar_mult_init(bases, curve)
+    assert ctx.run(sc)[0] == exp and ctx.last_timings()["launches"] == 1
+    need = ea.plan(n, curve)["work_bytes"]
+    ctx.set_option("mem_limit", need // 3)          # a third of what one chunk of n needs: four chunks of n/4
+    assert ctx.run(sc)[0] == exp
+    assert ctx.last_timings()["launches"] >= 3
+    ctx.set_option("mem_limit", 0)
+    assert ctx.run(sc)[0] == exp and ctx.last_timings()["launches"] == 1
+    ctx.close()
+
+
+def test_allocation_failure_halves_the_chunk_and_retries(ea, oracle):
+    n = 60000
+    bases = ea.generate_points(n, distinct=777, seed=9)
+    sc = _scalars(2 * n, 4)
+    exp = [oracle_msm_np(oracle, 0, bases, np.ascontiguousarray(sc[b * n:(b + 1) * n]), n) for b in range(2)]
+    ctx = ea.multi_scalar_mult_init(bases, "bls12_377_g1")
+    ctx.set_option("inject_alloc_failures", 1)       # the first buffer reservation of the next run fails
+    assert ctx.run(sc) == exp
+    assert ctx.query("oom_backoffs") == 1 and 0 < ctx.query("chunk_cap") <= (n + 1) // 2
+    assert ctx.last_timings()["launches"] >= 4       # two batches, each in (at least) two chunks now
+    # the cap stays until the options change; results stay
+    assert ctx.run(np.ascontiguousarray(sc[:n]))[0] == exp[0]
+    ctx.set_option("mem_limit", 0)                   # resets the cap
+    assert ctx.query("chunk_cap") == 0
+    assert ctx.run(np.ascontiguousarray(sc[n:]))[0] == exp[1] and ctx.last_timings()["launches"] == 1
+    ctx.close()
+
+
+def _failing_pair():
+    rng = random.Random(9)
+    for P in m.random_points(C, 8, rng):
+        for E in te.exceptional_points():
+            R = C.add(P, E)
+            a, b = te.sw_to_te(R), te.sw_to_te(P)
+            if a is None or b is None:
+                continue
+            if te.te_add(a, b) is None:
+                return R, P
+            if te.te_add(a, te.te_neg(b)) is None:
+                return R, C.neg(P)
+    raise AssertionError("no failing pair found")
+
+
+def test_two_fallbacks_in_a_row_demote_the_context(ea, oracle):
+    R, Q = _failing_pair()
+    rng = random.Random(4)
+    n = 3000
+    pts = m.random_points(C, 50, rng)
+    seq = [pts[i % 50] for i in range(n)]
+    seq[100], seq[2000] = R, Q
+    bases = np.frombuffer(C.encode_affine_array(seq), dtype=np.uint8).reshape(n, 104).copy()
+    bad = np.zeros((n, 32), dtype=np.uint8)
+    bad[100] = bad[2000] = _scalars(1, 5)[0]
+    good = _scalars(n, 6)
+    good[100] = 0
+    ctx = ea.multi_scalar_mult_init(bases, "bls12_377_g1")
+    assert ctx.query("twisted_edwards") == 1
+    exp_bad = oracle_msm_np(oracle, 0, bases, bad, n)
+    assert ctx.run(bad)[0] == exp_bad and ctx.query("twisted_edwards_fallbacks") == 1
+    # a clean run in between resets the streak
+    assert ctx.run(good)[0] == oracle_msm_np(oracle, 0, bases, good, n)
+    assert ctx.run(bad)[0] == exp_bad and ctx.query("twisted_edwards") == 1 and ctx.query("twisted_edwards_demotions") == 0
+    # two in a row: demoted, no further fallbacks are paid for
+    assert ctx.run(bad)[0] == exp_bad
+    assert ctx.query("twisted_edwards") == 0 and ctx.query("twisted_edwards_demotions") == 1
+    before = ctx.query("twisted_edwards_fallbacks")
+    assert ctx.run(bad)[0] == exp_bad and ctx.query("twisted_edwards_fallbacks") == before
+    assert ctx.last_timings()["twisted_edwards"] is False
+    # a new base set gets a new chance
+    ctx.set_bases(ea.generate_points(n, distinct=100, seed=3))
+    assert ctx.query("twisted_edwards") == 1
+    ctx.close()

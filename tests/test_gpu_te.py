@@ -1,4 +1,4 @@
-"""GPU: the twisted-Edwards fast path of BLS12-377 G1 (csrc/te.cuh) is an implementation detail that must never change a
+"""GPU: the twisted-Edwards fast path of BLS12-377 G1 (csrc/te.hpp) is an implementation detail that must never change a
 result: same bytes as the XYZZ path and as the oracle; base sets with a point the map is undefined on stay on XYZZ; an
 addition with a vanishing denominator (the curve's d is a square, so they exist off the prime-order subgroup) is detected
 on the device and the run is repeated on XYZZ -- also from a context whose short-Weierstrass tables were dropped."""

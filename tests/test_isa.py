@@ -17,7 +17,7 @@ HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
 
 def _compile_kernel(instantiation):
-    src = '#include "%s/2022-entries_amd/csrc/msm_kernels.cuh"\nnamespace msm {\n%s\n}\n' % (ROOT, instantiation)
+    src = '#include "%s/2022-entries_amd/csrc/msm_kernels.hpp"\nnamespace msm {\n%s\n}\n' % (ROOT, instantiation)
     with tempfile.TemporaryDirectory() as d:
         open(os.path.join(d, "acc.hip"), "w").write(src)
         r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++20", "-c", "acc.hip", "-o", "acc.o", "-save-temps",
@@ -39,11 +39,11 @@ def _compile_kernel(instantiation):
 @pytest.mark.parametrize("law", ["sw", "te"])
 def test_accumulate_kernel_isa(law):
     if law == "sw":
-        inst = ("template __global__ void k_accumulate_coop<SwLaw<FpEl<Bls12_377_Fq>>>(const uint32_t*, const uint32_t*, uint32_t, uint32_t, "
-                "uint32_t, const AffineDev*, SegOut, uint32_t, uint32_t*);")
+        inst = ("template __global__ void k_accumulate_coop<SwLaw<FpEl<Bls12_377_Fq>>>(const uint2*, const uint32_t*, uint32_t, "
+                "const AffineDev*, SegOut, uint32_t, uint32_t*);")
     else:
-        inst = ("template __global__ void k_accumulate_coop<TeLaw<Bls12_377_Fq>>(const uint32_t*, const uint32_t*, uint32_t, uint32_t, "
-                "uint32_t, const TeAffineDev*, SegOut, uint32_t, uint32_t*);")
+        inst = ("template __global__ void k_accumulate_coop<TeLaw<Bls12_377_Fq>>(const uint2*, const uint32_t*, uint32_t, "
+                "const TeAffineDev*, SegOut, uint32_t, uint32_t*);")
     body, ops, res = _compile_kernel(inst)
     assert "s_set_gpr_idx_on" not in body and "v_accvgpr" not in body
     assert body.count("scratch_") <= 8        # at most a couple of address registers parked outside the loop
@@ -60,3 +60,32 @@ def test_accumulate_kernel_isa(law):
     assert 256 * 128 <= res["lds"] <= 80 * 1024     # the record slots of the quad-cooperative gather; two blocks per CU fit in 160 KB
     # the gathers are 16-B per lane and the pieces cross lanes through LDS
     assert ops.count("ds_write_b128") >= 8 and ops.count("ds_read_b128") >= 7
+    # selects must be the VOP3 form: v_cndmask_b32_e32 (mask implicit in VCC) issues at 22.9 cycles on gfx950 against 4.2 for
+    # v_cndmask_b32_e64 (profiles/r02_ubench_valu_w4.txt); the sign handling of a mixed addition is 28-42 of them
+    assert ops.count("v_cndmask_b32_e32") <= 2, ops.count("v_cndmask_b32_e32")
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
+def test_partition_kernels_isa():
+    """The bucket-grouping kernels (csrc/partition.hpp): no scratch, the tile's scalars live in registers (<= 128 VGPRs at 1024
+    threads per block), LDS staging fits one block per CU with room to spare, and no library sort is linked."""
+    src = '#include "%s/2022-entries_amd/csrc/partition.hip"\n' % ROOT
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "part.hip"), "w").write(src)
+        r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++20", "-c", "part.hip", "-o", "part.o",
+                            "-Rpass-analysis=kernel-resource-usage"], cwd=d, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        remarks = r.stderr
+    seen = 0
+    for blk in remarks.split("Function Name: ")[1:]:
+        name = blk.split()[0]
+        scratch = int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", blk).group(1))
+        vgprs = int(re.search(r"VGPRs: (\d+)", blk).group(1))
+        lds = int(re.search(r"LDS Size \[bytes/block\]: (\d+)", blk).group(1))
+        assert scratch == 0, (name, scratch)
+        if "k_l1_scatter" in name or "k_pass_scatter" in name:
+            assert vgprs <= 128 and 64 * 1024 <= lds <= 120 * 1024, (name, vgprs, lds)
+            seen += 1
+    assert seen >= 5     # 4 instantiations of the level-1 scatter + the generic pass
+    blob = open(os.path.join(ROOT, "2022-entries_amd", "libmi355msm.so"), "rb").read()
+    assert b"rocprim" not in blob and b"k_l1_scatter" in blob and b"k_pass_scatter" in blob

@@ -197,3 +197,25 @@ def test_g2_oracle_vs_model():
         out = ctypes.create_string_buffer(288)
         assert lib.oracle_msm(2, c.encode_affine_array(pts), ctypes.c_size_t(200), m.encode_scalars(sc), ctypes.c_size_t(n), out, 0) == 0
         assert out.raw == c.encode_projective_normalized(c.msm_pippenger(pts, sc) if n > 40 else c.msm_naive(pts, sc)), n
+
+
+def test_g2_generator_and_twist_literals_pin_the_g2_oracle(golden_constants):
+    """The reference's own G2 literals (tests/golden/constants.json "bls12_377_g2", extracted from
+    ARKC bls12_377/src/curves/g2.rs:47-50, 61-78 and fields/fq2.rs:13): the generator satisfies y^2 = x^3 + b' over
+    Fq[u]/(u^2 + 5) and has order r -- checked in the Python model AND through the C oracle's own Fq2 arithmetic
+    (r * G = O and (r - 1) * G = -G via oracle_msm), so the G2 oracle is pinned to reference data, not only to pymodel."""
+    k = golden_constants["bls12_377_g2"]
+    c = m.BLS12_377_G2
+    gx, gy = (int(k["GX0"]), int(k["GX1"])), (int(k["GY0"]), int(k["GY1"]))
+    assert (gx, gy) == (tuple(c.gx), tuple(c.gy)) and tuple(c.b) == (int(k["B0"]), int(k["B1"])) and c.nonresidue == int(k["NONRESIDUE"])
+    p = c.p
+    X, Y, B = m.Fp2(gx[0], gx[1], p, p - 5), m.Fp2(gy[0], gy[1], p, p - 5), m.Fp2(int(k["B0"]), int(k["B1"]), p, p - 5)
+    assert Y * Y == X * X * X + B                                  # on the twist E'(Fq2)
+    G = c.generator()
+    assert c.on_curve(G) and c.mul(c.r, G) is None                 # in the order-r subgroup (ARK test-templates/src/lib.rs:42-47)
+    lib = ctypes.CDLL(os.path.join(ROOT, "oracle", "liboracle.so"))
+    base = c.encode_affine_array([G])
+    for scalar, expect in ((c.r, None), (c.r - 1, c.neg(G)), (1, G)):
+        out = ctypes.create_string_buffer(288)
+        assert lib.oracle_msm(2, base, ctypes.c_size_t(200), m.encode_scalars([scalar]), ctypes.c_size_t(1), out, 0) == 0
+        assert out.raw == c.encode_projective_normalized(expect), scalar

@@ -1,0 +1,83 @@
+"""CPU: the Rust crate under rust/ is text in this image (no cargo/rustc) -- so pin it to the built libraries instead: every
+`extern "C"` item declared in rust/src/lib.rs must be exported (`nm -D`) by the shared object build.rs links it from, with the
+arity the C header / shim declares, and the operator API must have the reference's names and shapes
+(P1A 6block/src/lib.rs:18-21, 54-109; ARK ec/src/msm/variable_base/mod.rs:44-65)."""
+import os
+import re
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+RUST = os.path.join(ROOT, "rust")
+PKG = os.path.join(ROOT, "2022-entries_amd")
+
+
+def _extern_items(src):
+    """name -> number of parameters, for every fn inside an `extern "C" { ... }` block."""
+    items = {}
+    for block in re.findall(r'extern\s+"C"\s*\{(.*?)\n\s*\}', src, flags=re.S):
+        for name, params in re.findall(r"fn\s+(\w+)\s*\((.*?)\)\s*(?:->\s*[\w:]+)?\s*;", block, flags=re.S):
+            params = params.strip().rstrip(",")
+            items[name] = 0 if not params else len([p for p in params.split(",") if p.strip()])
+    return items
+
+
+def _c_decls(*paths):
+    decls = {}
+    for p in paths:
+        src = re.sub(r"/\*.*?\*/", "", open(p).read(), flags=re.S)
+        for name, params in re.findall(r"\b(\w+)\s*\(([^;{}()]*)\)\s*;", src):
+            params = params.strip()
+            decls[name] = 0 if params in ("", "void") else len(params.split(","))
+    return decls
+
+
+def _exports(lib):
+    out = subprocess.run(["nm", "-D", "--defined-only", lib], capture_output=True, text=True, check=True).stdout
+    return {line.split()[-1] for line in out.splitlines() if line.strip()}
+
+
+def test_crate_files_present():
+    for f in ("Cargo.toml", "build.rs", "src/lib.rs", "src/util.rs", "tests/msm.rs", "benches/msm.rs"):
+        assert os.path.exists(os.path.join(RUST, f)), f
+    toml = open(os.path.join(RUST, "Cargo.toml")).read()
+    for dep in ('ark-ec = { version = "0.3.0"', 'ark-ff = "0.3.0"', 'ark-bls12-377 = { version = "0.3.0"'):
+        assert dep in toml      # the versions the reference pins
+    build = open(os.path.join(RUST, "build.rs")).read()
+    assert "mi355msm_zprize_377" in build and "mi355msm_zprize_381" in build and "rustc-link-lib=dylib=mi355msm" in build
+
+
+def test_extern_items_match_exported_symbols(built):
+    src = open(os.path.join(RUST, "src", "lib.rs")).read()
+    items = _extern_items(src)
+    assert {"mult_pippenger_init", "mult_pippenger_inf", "mi355_msm_create_sharded", "mi355_msm_run", "mi355_msm_fold"} <= set(items)
+    shim = _exports(os.path.join(PKG, "libmi355msm_zprize_377.so")) | _exports(os.path.join(PKG, "libmi355msm_zprize_381.so"))
+    core = _exports(os.path.join(PKG, "libmi355msm.so"))
+    decls = _c_decls(os.path.join(ROOT, "include", "mi355_msm.h"))
+    # the shim header guards its declarations behind macros: read the flavour the crate links
+    shim_src = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "mi355_msm_shims.h")).read(), flags=re.S)
+    zp = shim_src[shim_src.index("#if defined(MI355_SHIM_ZPRIZE)"):]
+    zp = zp[:zp.index("#endif")]
+    for name, params in re.findall(r"\b(\w+)\s*\(([^;{}()]*)\)\s*;", zp):
+        decls[name] = len(params.split(","))
+    for name, arity in items.items():
+        if name == "free":
+            continue
+        where = shim if name.startswith("mult_pippenger") else core
+        assert name in where, f"rust/src/lib.rs declares {name}, which the linked library does not export"
+        assert decls.get(name) == arity, f"{name}: {arity} parameters in Rust, {decls.get(name)} in the C declaration"
+
+
+def test_operator_api_has_the_reference_shapes():
+    src = open(os.path.join(RUST, "src", "lib.rs")).read()
+    assert re.search(r"#\[repr\(C\)\]\s*pub struct MultiScalarMultContext\s*\{\s*context:\s*\*mut c_void,\s*\}", src)
+    assert re.search(r"pub fn multi_scalar_mult_init<G: AffineCurve>\(\s*points: &\[G\]\s*\)\s*->\s*MultiScalarMultContext", src)
+    assert re.search(r"pub fn multi_scalar_mult<G: AffineCurve>\(\s*context: &mut MultiScalarMultContext,\s*points: &\[G\],\s*"
+                     r"scalars: &\[<G::ScalarField as PrimeField>::BigInt\],\s*\)\s*->\s*Vec<G::Projective>", src)
+    for fn in ("pub fn msm(", "pub fn msm_checked(", "pub fn msm_bigint("):
+        assert fn in src
+    assert "Result<G1Projective, usize>" in src
+    test = open(os.path.join(RUST, "tests", "msm.rs")).read()
+    assert "VariableBaseMSM::multi_scalar_mul" in test and "into_affine()" in test and "batches = 4" in test

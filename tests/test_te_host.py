@@ -1,4 +1,4 @@
-"""CPU: the twisted-Edwards image of BLS12-377 G1 (csrc/te.cuh) compiled for the host with the limb-bound checker armed,
+"""CPU: the twisted-Edwards image of BLS12-377 G1 (csrc/te.hpp) compiled for the host with the limb-bound checker armed,
 against two independent big-int models: oracle/te_model.py (the map and the Edwards law, derived from first principles) and
 oracle/pymodel.py (short-Weierstrass chord-and-tangent).  What is pinned: the birational map and its five exceptional
 points, the 7M mixed addition incl. negated bases and the identity, the unified 9M addition used as doubling, the map back,

@@ -9,7 +9,7 @@ for r in $(seq $ROUNDS); do
   for v in 2022-entries_amd/build/variants/*.so; do
     cp $v $LIB
     echo -n "$(basename $v .so) r$r: "
-    timeout 300 python bench.py --steps 6 --warmup 2 --cpu-sample-pow 0 --also-precompute 0 "$@" | python -c "
+    timeout 300 python bench.py --steps 6 --warmup 2 --cpu-sample-pow 0 --extras 0 --also-precompute 0 "$@" | python -c "
 import json,sys
 j=json.loads(sys.stdin.read().strip().splitlines()[-1]); s=j['stage_ms_per_step']
 print('step %.2f ms  accumulate %.2f  sort %.2f  reduce %.2f' % (j['ms_per_step'], s['accumulate'], s['sort'], s['bucket_reduce']))"

@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Pull the BLS12-377 G2 literals the reference holds -- generator coordinates, the twist coefficient b' and the Fq2
+non-residue -- out of its sources into tests/golden/constants.json (data, not code; run in the build container only:
+/root/reference does not exist on the GPU box).
+
+  ARKC bls12_377/src/curves/g2.rs:47-50   COEFF_B = (0, 1551...906)
+  ARKC bls12_377/src/curves/g2.rs:61-78   G2_GENERATOR_{X,Y}_{C0,C1}
+  ARKC bls12_377/src/fields/fq2.rs:13     NONRESIDUE = -5
+"""
+import json
+import os
+import re
+
+ARKC = "/root/reference/open-division/prize4-msm-wasm/snarkify/zprize-prize4-15ac8c55-arkworks-curves/bls12_377/src"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def main():
+    g2 = open(os.path.join(ARKC, "curves", "g2.rs")).read()
+    fq2 = open(os.path.join(ARKC, "fields", "fq2.rs")).read()
+    out = {}
+    for name in ("X_C0", "X_C1", "Y_C0", "Y_C1"):
+        mm = re.search(r"pub const G2_GENERATOR_%s: Fq = MontFp!\(\"(\d+)\"\);" % name, g2)
+        out["G" + name.replace("_C", "")] = mm.group(1)
+    mm = re.search(r"const COEFF_B: Fq2 = Fq2::new\(\s*Fq::ZERO,\s*MontFp!\(\"(\d+)\"\),\s*\);", g2)
+    out["B0"], out["B1"] = "0", mm.group(1)
+    mm = re.search(r"const NONRESIDUE: Fq = MontFp!\(\"(-?\d+)\"\);", fq2)
+    out["NONRESIDUE"] = mm.group(1)
+    path = os.path.join(ROOT, "tests", "golden", "constants.json")
+    data = json.load(open(path))
+    data["bls12_377_g2"] = out
+    data["source_g2"] = ("ARKC bls12_377/src/curves/g2.rs:47-50 (COEFF_B), :61-78 (generator), fields/fq2.rs:13 (NONRESIDUE); "
+                         "decimal literals, normal form; extracted by tools/extract_g2_consts.py")
+    with open(path, "w") as f:
+        json.dump(data, f, indent=1)
+        f.write("\n")
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()

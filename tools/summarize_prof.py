@@ -10,7 +10,8 @@ root = sys.argv[1]
 
 
 def short(name):
-    for k in ("k_accumulate", "k_segreduce", "k_bucket_reduce", "k_digits", "k_convert_bases"):
+    for k in ("k_accumulate", "k_segreduce", "k_bucket_reduce", "k_l1_hist", "k_l1_scatter", "k_l1_scan", "k_l1_merge", "k_pass_hist", "k_pass_scan",
+              "k_pass_scatter", "k_pass_subjobs", "k_digits", "k_convert_bases"):
         if k in name:
             return k + ("<381>" if "381" in name else "<377>" if "377" in name else "")
     if "rocprim" in name or "radix" in name or "onesweep" in name:

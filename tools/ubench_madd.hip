@@ -1,7 +1,7 @@
 // ubench_madd.hip -- mixed-addition throughput in isolation (operands in registers, no memory traffic) for the two group laws:
-// XYZZ (8M + 2S, curve.cuh) and extended twisted Edwards (7M, te.cuh), at the occupancy k_accumulate runs at.
+// XYZZ (8M + 2S, curve.hpp) and extended twisted Edwards (7M, te.hpp), at the occupancy k_accumulate runs at.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++20 tools/ubench_madd.hip -o tools/ubench_madd && tools/ubench_madd
-#include "../2022-entries_amd/csrc/laws.cuh"
+#include "../2022-entries_amd/csrc/laws.hpp"
 #include <cstdio>
 #include <cstdlib>
 using namespace msm;

@@ -2,7 +2,7 @@
 // v_mad_u64_u32 chains) against the same product scanning written as plain C++ loops (what hipcc schedules by itself).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++20 tools/ubench_mul.hip -o tools/ubench_mul && tools/ubench_mul
 // Results of record: profiles/r01_ubench_mul.txt.
-#include "../2022-entries_amd/csrc/fp28.cuh"
+#include "../2022-entries_amd/csrc/fp28.hpp"
 #include <cstdio>
 #include <cstdlib>
 using namespace msm;

@@ -53,6 +53,14 @@ KERNEL(k_cndmask_sgpr, asm volatile("v_cndmask_b32 %0, %0, %4, s[10:11]\n\tv_cnd
 KERNEL(k_mad_u64_u32_sconst, asm volatile("v_mad_u64_u32 %0, vcc, s20, %5, %0\n\tv_mad_u64_u32 %1, vcc, s20, %5, %1\n\tv_mad_u64_u32 %2, vcc, s20, %5, %2\n\tv_mad_u64_u32 %3, vcc, s20, %5, %3" : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3) : "v"(b), "v"(c) : "vcc", "s20");)
 KERNEL(k_mad_u64_u32_sgpr, asm volatile("v_mad_u64_u32 %0, s[10:11], %4, %5, %0\n\tv_mad_u64_u32 %1, s[12:13], %4, %5, %1\n\tv_mad_u64_u32 %2, s[10:11], %4, %5, %2\n\tv_mad_u64_u32 %3, s[12:13], %4, %5, %3" : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3) : "v"(b), "v"(c) : "s10", "s11", "s12", "s13");)
 
+KERNEL(k_cndmask_e64_vcc, asm volatile("v_cndmask_b32_e64 %0, %0, %4, vcc\n\tv_cndmask_b32_e64 %1, %1, %4, vcc\n\tv_cndmask_b32_e64 %2, %2, %4, vcc\n\tv_cndmask_b32_e64 %3, %3, %4, vcc" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b) : "vcc");)
+KERNEL(k_cndmask_cmp, asm volatile("v_cmp_gt_u32_e32 vcc, %4, %0\n\tv_cndmask_b32_e32 %0, %0, %4, vcc\n\tv_cndmask_b32_e32 %1, %1, %4, vcc\n\tv_cndmask_b32_e32 %2, %2, %4, vcc\n\tv_cndmask_b32_e32 %3, %3, %4, vcc" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b) : "vcc");)
+KERNEL(k_cndmask_distinct, asm volatile("v_cndmask_b32_e32 %0, %5, %4, vcc\n\tv_cndmask_b32_e32 %1, %5, %4, vcc\n\tv_cndmask_b32_e32 %2, %5, %4, vcc\n\tv_cndmask_b32_e32 %3, %5, %4, vcc" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b), "v"(c) : "vcc");)
+KERNEL(k_xad_u32, asm volatile("v_xad_u32 %0, %0, %4, %5\n\tv_xad_u32 %1, %1, %4, %5\n\tv_xad_u32 %2, %2, %4, %5\n\tv_xad_u32 %3, %3, %4, %5" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b), "v"(c));)
+KERNEL(k_bfi_b32, asm volatile("v_bfi_b32 %0, %0, %4, %5\n\tv_bfi_b32 %1, %1, %4, %5\n\tv_bfi_b32 %2, %2, %4, %5\n\tv_bfi_b32 %3, %3, %4, %5" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b), "v"(c));)
+KERNEL(k_mad_nop_shift, asm volatile("v_mad_u64_u32 %0, vcc, %4, %5, %0\n\ts_nop 0\n\tv_lshrrev_b64 %1, 28, %0\n\tv_mad_u64_u32 %2, vcc, %4, %5, %2\n\ts_nop 0\n\tv_lshrrev_b64 %3, 28, %2" : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3) : "v"(b), "v"(c) : "vcc");)
+KERNEL(k_mad_shift, asm volatile("v_mad_u64_u32 %0, vcc, %4, %5, %0\n\tv_lshrrev_b64 %1, 28, %0\n\tv_mad_u64_u32 %2, vcc, %4, %5, %2\n\tv_lshrrev_b64 %3, 28, %2" : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3) : "v"(b), "v"(c) : "vcc");)
+
 typedef void (*kern_t)(uint32_t*, int);
 struct Row { const char* name; kern_t k; };
 
@@ -74,7 +82,10 @@ int main(int argc, char** argv) {
     {"v_mad_u64_u32+v_addc (pair=2 instr)", k_mad_u64_u32_addc},
     {"v_lshl_add_u64", k_lshl_add_u64}, {"v_lshrrev_b64", k_lshrrev_b64}, {"v_and_b32", k_and_b32}, {"v_sub_u32", k_sub_u32},
     {"v_lshrrev_b32", k_lshrrev_b32}, {"v_add3_u32", k_add3_u32}, {"v_and_or_b32", k_and_or_b32}, {"v_cndmask_b32 (sgpr mask)", k_cndmask_sgpr},
-    {"v_mad_u64_u32 (sgpr operand)", k_mad_u64_u32_sconst}, {"v_fma_f64", k_fma_f64}, {"v_mul_f64", k_mul_f64}, {"v_add_f64", k_add_f64},
+    {"v_mad_u64_u32 (sgpr operand)", k_mad_u64_u32_sconst},
+    {"v_cndmask_b32_e64 (vcc mask)", k_cndmask_e64_vcc}, {"v_cmp + 4 v_cndmask_e32 (5 instr)", k_cndmask_cmp},
+    {"v_cndmask_b32_e32 dst != src", k_cndmask_distinct}, {"v_xad_u32", k_xad_u32}, {"v_bfi_b32", k_bfi_b32},
+    {"mad,s_nop,lshr64 x2 (6 instr, 4 VALU)", k_mad_nop_shift}, {"mad,lshr64 x2 (4 instr)", k_mad_shift}, {"v_fma_f64", k_fma_f64}, {"v_mul_f64", k_mul_f64}, {"v_add_f64", k_add_f64},
   };
   hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
   printf("%-40s %10s %14s %16s\n", "instruction", "ms", "cyc/wave-instr", "Glane-ops/s");
