@@ -258,14 +258,14 @@ int ht_add_chains(int curve, const uint8_t* pts, size_t stride, size_t na, size_
 int ht_msm_naive(int curve, const uint8_t* pts, size_t stride, const uint8_t* scalars, size_t n, uint8_t* out) { DISPATCH_C(curve, t_msm_naive, pts, stride, scalars, n, out) }
 int ht_normalize(int curve, const uint8_t* in, uint8_t* out) { DISPATCH_C(curve, t_normalize, in, out) }
 
-// (X, Y, 2dXY) of the image of an arkworks Affine image, as three ABI Montgomery field images; 1 = no image.
+// (Y - X, Y + X, 2dXY) -- the base record -- of the image of an arkworks Affine image, as three ABI Montgomery field images; 1 = no image.
 int ht_te_map(const uint8_t* img, uint8_t* out) {
   Modulus<TF> md;
   TeAffine t;
   if (!te_map_host(t, img, md)) return 1;
   uint32_t w[36];
-  fe_to_abi<TF>(w, t.x, md);
-  fe_to_abi<TF>(w + 12, t.y, md);
+  fe_to_abi<TF>(w, t.ymx, md);
+  fe_to_abi<TF>(w + 12, t.ypx, md);
   fe_to_abi<TF>(w + 24, t.td, md);
   memcpy(out, w, 144);
   return 0;

@@ -238,16 +238,7 @@ __global__ void __launch_bounds__(256, G::ACC_WAVES) k_accumulate_coop(const uin
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      const uint4* mine = reinterpret_cast<const uint4*>(lds + threadIdx.x * LS);
-      uint32_t* dst = reinterpret_cast<uint32_t*>(&p);
-#pragma unroll
-      for (int q = 0; q < PIECES; q++) {
-        const uint4 v = mine[q];
-        if (4 * q < (int)(sizeof(Base) / 4)) dst[4 * q] = v.x;
-        if (4 * q + 1 < (int)(sizeof(Base) / 4)) dst[4 * q + 1] = v.y;
-        if (4 * q + 2 < (int)(sizeof(Base) / 4)) dst[4 * q + 2] = v.z;
-        if (4 * q + 3 < (int)(sizeof(Base) / 4)) dst[4 * q + 3] = v.w;
-      }
+      G::load_record(p, lds + threadIdx.x * LS, alive && (val_c >> 31) != 0);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -273,7 +264,7 @@ __global__ void __launch_bounds__(256, G::ACC_WAVES) k_accumulate_coop(const uin
         fresh = true;
         G::begin_run(acc);
       }
-      G::madd(acc, p, (val >> 31) != 0, fresh, md);
+      G::madd_loaded(acc, p, (val >> 31) != 0, fresh, md);
       if (G::CHECKS) bad |= G::failed(acc);
       fresh = false;
     }
@@ -480,8 +471,8 @@ __global__ void __launch_bounds__(256) k_te_convert(const AffineDev* __restrict_
   fe_inv<F>(inv, run, md);
   for (uint64_t j = hi; j-- > lo;) {
     TeAffineDev o;
-    fe_zero(o.p.x);
-    fe_set(o.p.y, F::ONE);
+    fe_set(o.p.ymx, F::ONE);   // the identity (0, 1): a harmless filler
+    fe_set(o.p.ypx, F::ONE);
     fe_zero(o.p.td);
     if (!inf[j]) {
       const AffineDev a = in[j];

@@ -93,6 +93,15 @@ __device__ __forceinline__ void load_scalar(ScalarDigits& st, const uint32_t* __
   st.carry = 0;
 }
 
+// Tile of a level-1 block.  Workgroup b runs on XCD b % 8 (observed placement; used for speed only): give every XCD a CONTIGUOUS
+// range of tiles, so that the tiles in flight on one XCD are neighbours.  Neighbouring tiles write neighbouring runs of every
+// bin (the offsets are a column scan over tiles), and runs that share a 128-B line then meet in the same L2 before they are
+// written back -- with the plain b -> tile map they would sit in eight different, non-coherent L2s as partial lines.
+__device__ __forceinline__ uint32_t l1_tile(uint32_t block, uint32_t ntiles) {
+  const uint32_t per_xcd = (ntiles + 7) >> 3;
+  return (block & 7) * per_xcd + (block >> 3);
+}
+
 // Level-1 bin of (window w, bucket b): window-major normally; bucket-major with shared buckets, so that the W runs of one
 // bucket range are neighbours and form ONE segment for the next pass.
 __device__ __forceinline__ uint32_t l1_bin(const PartPlan& p, uint32_t w, uint32_t bucket) {
@@ -106,10 +115,12 @@ template <class FR, bool MONT>
 __global__ void __launch_bounds__(PART_THREADS) k_l1_hist(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ inf, PartPlan p,
                                                           uint32_t* __restrict__ matrix) {
   extern __shared__ uint32_t hist[];   // nbins
+  const uint32_t tile = l1_tile(blockIdx.x, p.ntiles);
+  if (tile >= p.ntiles) return;
   for (uint32_t b = threadIdx.x; b < p.nbins; b += PART_THREADS) hist[b] = 0;
   __syncthreads();
   const uint32_t wmask = (1u << p.c) - 1;
-  const uint32_t i0 = blockIdx.x * PART_TILE;
+  const uint32_t i0 = tile * PART_TILE;
 #pragma unroll 1
   for (int k = 0; k < PART_PER_THREAD; k++) {
     const uint32_t i = i0 + threadIdx.x + k * PART_THREADS;
@@ -127,7 +138,7 @@ __global__ void __launch_bounds__(PART_THREADS) k_l1_hist(const uint32_t* __rest
     }
   }
   __syncthreads();
-  uint32_t* row = matrix + (size_t)blockIdx.x * p.nbins;
+  uint32_t* row = matrix + (size_t)tile * p.nbins;
   for (uint32_t b = threadIdx.x; b < p.nbins; b += PART_THREADS) row[b] = hist[b];
 }
 
@@ -242,16 +253,17 @@ __global__ void __launch_bounds__(256) k_l1_merge_shared(const PartSeg* __restri
 }
 
 // L1 scatter: one block per tile; the tile's scalars stay in registers while the windows are processed one after the other.
-// LDS: stage (8192 x u64) + bin of every staged entry (u16) + three (b1 + 1)-word arrays.
+// LDS: stage (8192 x u64; the bin rides in the high half of the key word until the entry leaves) + three (b1 + 1)-word arrays.
 template <class FR, bool MONT>
 __global__ void __launch_bounds__(PART_THREADS) k_l1_scatter(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ inf, PartPlan p,
                                                              const uint32_t* __restrict__ matrix, uint2* __restrict__ out) {
   __shared__ uint2 stage[PART_TILE];
-  __shared__ uint16_t sbin[PART_TILE];
   __shared__ uint32_t offs[1 << PART_MAX_HB], cnt[1 << PART_MAX_HB], tstart[(1 << PART_MAX_HB) + 1];
   __shared__ uint32_t tmp[32];
+  const uint32_t tile = l1_tile(blockIdx.x, p.ntiles);
+  if (tile >= p.ntiles) return;
   const uint32_t wmask = (1u << p.c) - 1, lowmask = (1u << p.lb) - 1;
-  const uint32_t i0 = blockIdx.x * PART_TILE;
+  const uint32_t i0 = tile * PART_TILE;
   ScalarDigits st[PART_PER_THREAD];
   uint32_t alive = 0;     // bit k: scalar k exists and (without tables) its base is not flagged infinite
 #pragma unroll
@@ -266,11 +278,15 @@ __global__ void __launch_bounds__(PART_THREADS) k_l1_scatter(const uint32_t* __r
       st[k].carry = 0;
     }
   }
-  const uint32_t* row = matrix + (size_t)blockIdx.x * p.nbins;
+  const uint32_t* row = matrix + (size_t)tile * p.nbins;
+  // the run offsets of the next window are fetched a whole window step ahead (a global load in the step's critical path
+  // would cost ~1.5 us of the ~10 us a step takes)
+  uint32_t offs_next = threadIdx.x < p.b1 ? row[p.shared ? threadIdx.x * p.windows : threadIdx.x] : 0;
   for (uint32_t w = 0; w < p.windows; w++) {
-    for (uint32_t b = threadIdx.x; b < p.b1; b += PART_THREADS) {
-      cnt[b] = 0;
-      offs[b] = row[p.shared ? b * p.windows + w : w * p.b1 + b];
+    if (threadIdx.x < p.b1) {
+      cnt[threadIdx.x] = 0;
+      offs[threadIdx.x] = offs_next;
+      if (w + 1 < p.windows) offs_next = row[p.shared ? threadIdx.x * p.windows + (w + 1) : (w + 1) * p.b1 + threadIdx.x];
     }
     __syncthreads();
     uint32_t where[PART_PER_THREAD];   // bin << 16 | rank in the tile's bin; 0xffffffff = no entry
@@ -289,7 +305,7 @@ __global__ void __launch_bounds__(PART_THREADS) k_l1_scatter(const uint32_t* __r
         const uint32_t bucket = mag - 1, hi = bucket >> p.lb;
         const uint32_t rank = atomicAdd(&cnt[hi], 1u);
         where[k] = (hi << 16) | rank;
-        ent[k] = make_uint2(idx | (neg ? 0x80000000u : 0u), bucket & lowmask);
+        ent[k] = make_uint2(idx | (neg ? 0x80000000u : 0u), (bucket & lowmask) | (hi << 16));   // lb <= 15
       }
     }
     __syncthreads();
@@ -303,18 +319,15 @@ __global__ void __launch_bounds__(PART_THREADS) k_l1_scatter(const uint32_t* __r
     }
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < PART_PER_THREAD; k++) {
-      if (where[k] != 0xffffffffu) {
-        const uint32_t hi = where[k] >> 16, pos = tstart[hi] + (where[k] & 0xffffu);
-        stage[pos] = ent[k];
-        sbin[pos] = (uint16_t)hi;
-      }
-    }
+    for (int k = 0; k < PART_PER_THREAD; k++)
+      if (where[k] != 0xffffffffu) stage[tstart[where[k] >> 16] + (where[k] & 0xffffu)] = ent[k];
     __syncthreads();
     const uint32_t total = tstart[p.b1];
     for (uint32_t j = threadIdx.x; j < total; j += PART_THREADS) {
-      const uint32_t hi = sbin[j];
-      out[offs[hi] + (j - tstart[hi])] = stage[j];
+      uint2 e = stage[j];
+      const uint32_t hi = e.y >> 16;
+      e.y &= 0xffffu;
+      out[offs[hi] + (j - tstart[hi])] = e;
     }
     __syncthreads();
   }
@@ -407,12 +420,13 @@ __global__ void __launch_bounds__(1024) k_pass_subjobs(const PartSeg* __restrict
   }
 }
 
-// Scatter of one sub-job: LDS multisplit tile by tile, cursors of the sub-job in LDS, runs written contiguously.
-__global__ void __launch_bounds__(1024) k_pass_scatter(const uint2* __restrict__ in, const PartSeg* __restrict__ segs,
-                                                       const uint32_t* __restrict__ subjob_first, PassPlan pp,
-                                                       const uint32_t* __restrict__ positions, uint2* __restrict__ out) {
+// Scatter of one sub-job: LDS multisplit tile by tile, cursors of the sub-job in LDS, runs written contiguously; the next
+// tile's entries are already in flight while the current one is split.  What bounds it is not LDS or issue but how many
+// partially written 128-B lines the XCD's 4-MB L2 has to keep open (bins x concurrent blocks): hence big tiles, one block per CU.
+__global__ void __launch_bounds__(1024, PART_PASS_OCC) k_pass_scatter(const uint2* __restrict__ in, const PartSeg* __restrict__ segs,
+                                                          const uint32_t* __restrict__ subjob_first, PassPlan pp,
+                                                          const uint32_t* __restrict__ positions, uint2* __restrict__ out) {
   __shared__ uint2 stage[PART_PTILE];
-  __shared__ uint16_t sbin[PART_PTILE];
   __shared__ uint32_t cur[1 << PART_MAX_RB], cnt[1 << PART_MAX_RB], tstart[(1 << PART_MAX_RB) + 1];
   __shared__ uint32_t tmp[32];
   const uint32_t nb = 1u << pp.rb, shift = pp.rem - pp.rb, keepmask = (1u << shift) - 1;
@@ -423,22 +437,33 @@ __global__ void __launch_bounds__(1024) k_pass_scatter(const uint2* __restrict__
   const uint32_t* row = positions + (size_t)blockIdx.x * nb;
   for (uint32_t b = threadIdx.x; b < nb; b += 1024) cur[b] = row[b];
   constexpr int PER = PART_PTILE / 1024;
+  uint2 nxt[PER];
+#pragma unroll
+  for (int k = 0; k < PER; k++) {
+    const uint32_t e = beg + threadIdx.x + k * 1024;
+    if (e < end) nxt[k] = in[e];
+  }
   for (uint32_t t0 = beg; t0 < end; t0 += PART_PTILE) {
     for (uint32_t b = threadIdx.x; b < nb; b += 1024) cnt[b] = 0;
-    __syncthreads();
     uint2 ent[PER];
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+      ent[k] = nxt[k];
+      const uint32_t e = t0 + PART_PTILE + threadIdx.x + k * 1024;
+      if (e < end) nxt[k] = in[e];
+    }
+    __syncthreads();
     uint32_t where[PER];
 #pragma unroll
     for (int k = 0; k < PER; k++) {
       const uint32_t e = t0 + threadIdx.x + k * 1024;
       where[k] = 0xffffffffu;
       if (e < end) {
-        ent[k] = in[e];
         const uint32_t bin = (ent[k].y >> shift) & (nb - 1);
         const uint32_t rank = atomicAdd(&cnt[bin], 1u);
         where[k] = (bin << 16) | rank;
-        // high word: the bits still unresolved, or -- after the last pass -- the full key
-        ent[k].y = pp.last ? key_base + bin : (ent[k].y & keepmask);
+        // key word while staged: the bits still unresolved (< 2^16) with the bin above them
+        ent[k].y = (ent[k].y & keepmask) | (bin << 16);
       }
     }
     __syncthreads();
@@ -451,22 +476,20 @@ __global__ void __launch_bounds__(1024) k_pass_scatter(const uint2* __restrict__
     }
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < PER; k++) {
-      if (where[k] != 0xffffffffu) {
-        const uint32_t bin = where[k] >> 16, pos = tstart[bin] + (where[k] & 0xffffu);
-        stage[pos] = ent[k];
-        sbin[pos] = (uint16_t)bin;
-      }
-    }
+    for (int k = 0; k < PER; k++)
+      if (where[k] != 0xffffffffu) stage[tstart[where[k] >> 16] + (where[k] & 0xffffu)] = ent[k];
     __syncthreads();
     const uint32_t total = tstart[nb];
     for (uint32_t j = threadIdx.x; j < total; j += 1024) {
-      const uint32_t bin = sbin[j];
-      out[cur[bin] + (j - tstart[bin])] = stage[j];
+      uint2 e = stage[j];
+      const uint32_t bin = e.y >> 16;
+      // leaving: after the last pass the key word is the full key, before it the bits the next pass will look at
+      e.y = pp.last ? key_base + bin : (e.y & 0xffffu);
+      out[cur[bin] + (j - tstart[bin])] = e;
     }
     __syncthreads();
     for (uint32_t b = threadIdx.x; b < nb; b += 1024) cur[b] += cnt[b];
-    // (the zeroing of cnt at the top of the next tile is ordered behind this update by its own barrier)
+    // (the zeroing of cnt at the top of the next tile is ordered behind this update by the barrier that follows it)
     __syncthreads();
   }
 }
@@ -484,7 +507,8 @@ inline int part_run(const uint32_t* d_scalars, const uint8_t* d_inf, const PartP
   err = hipSuccess;
   const uint64_t entries = (uint64_t)p.n * p.windows;
   const dim3 scan_grid(part_ceil_div(p.nbins, 256), PART_SCAN_GROUPS);
-  hipLaunchKernelGGL((k_l1_hist<FR, MONT>), dim3(p.ntiles), dim3(PART_THREADS), p.nbins * 4, st, d_scalars, d_inf, p, b.matrix);
+  const uint32_t l1_grid = 8 * ((p.ntiles + 7) / 8);   // l1_tile(): a contiguous tile range per XCD
+  hipLaunchKernelGGL((k_l1_hist<FR, MONT>), dim3(l1_grid), dim3(PART_THREADS), p.nbins * 4, st, d_scalars, d_inf, p, b.matrix);
   hipLaunchKernelGGL(k_l1_scan_a, scan_grid, dim3(256), 0, st, b.matrix, p, b.partial);
   hipLaunchKernelGGL(k_l1_scan_b, dim3(1), dim3(1024), 0, st, b.partial, p, b.segs[0], b.subjob_first, b.totals);
   hipLaunchKernelGGL(k_l1_scan_c, scan_grid, dim3(256), 0, st, b.matrix, p, b.partial);
@@ -495,7 +519,7 @@ inline int part_run(const uint32_t* d_scalars, const uint8_t* d_inf, const PartP
     seg_cur = 1;
     nsegs = p.b1;
   }
-  hipLaunchKernelGGL((k_l1_scatter<FR, MONT>), dim3(p.ntiles), dim3(PART_THREADS), 0, st, d_scalars, d_inf, p, b.matrix, b.entries[0]);
+  hipLaunchKernelGGL((k_l1_scatter<FR, MONT>), dim3(l1_grid), dim3(PART_THREADS), 0, st, d_scalars, d_inf, p, b.matrix, b.entries[0]);
   if (mid) (void)hipEventRecord(mid, st);
   uint32_t rb[4];
   const int np = part_pass_bits(p.lb, rb);

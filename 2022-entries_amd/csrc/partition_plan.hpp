@@ -15,7 +15,15 @@ constexpr int PART_PER_THREAD = PART_TILE / PART_THREADS;
 constexpr int PART_MAX_HB = 9;         // level-1 bins per window: 2^HB <= 512
 constexpr int PART_MAX_RB = 10;        // bins of one generic pass: 2^RB <= 1024
 constexpr uint32_t PART_SUBJOB = 192u << 10;   // entries per sub-job of a generic pass
-constexpr int PART_PTILE = 8192;       // entries per LDS-staged tile of a generic pass
+#ifndef PART_PTILE_V
+#define PART_PTILE_V 16384
+#endif
+#ifndef PART_PASS_OCC
+#define PART_PASS_OCC 4
+#endif
+// 16384-entry tiles (128 KB of LDS, one block per CU) give 16-entry / 128-B runs at 1024 bins; measured at 2^26 against 8192-entry
+// tiles with two blocks per CU: 6.5 vs 7.5 ms for the pass (profiles/r02_partition_tiles.txt)
+constexpr int PART_PTILE = PART_PTILE_V;       // entries per LDS-staged tile of a generic pass
 constexpr int PART_SCAN_GROUPS = 64;   // tile groups of the level-1 column scan
 
 struct PartSeg {          // a run of entries that share their high key bits

@@ -16,14 +16,16 @@
 //     checks it after each addition and raises a flag, and the engine then repeats the run on the XYZZ path.
 //
 // Extended points reuse XyzzT<Fe>: x = X, y = Y, zz = Z, zzz = T with X Y = Z T; all four are class M (strictly normalized
-// limbs, value < 1.5p).  Base records hold (X, Y, 2 d X Y), canonical.
+// limbs, value < 1.5p).  Base records hold (Y - X, Y + X, 2 d X Y), canonical: what the mixed addition multiplies by, so the
+// hot loop neither forms them (42 limb operations per addition) nor selects between them for a negated base -- -(X, Y) =
+// (-X, Y) swaps the first two, and a lane that reads its record out of LDS swaps two ADDRESSES instead of 28 registers.
 #pragma once
 #include "curve.hpp"
 
 namespace msm {
 
 struct TeAffine {
-  Fe x, y, td;
+  Fe ymx, ypx, td;   // Y - X, Y + X, 2 d X Y
 };
 // 168 B padded to three 64-B sectors, so one lane's gather touches exactly three
 struct alignas(64) TeAffineDev {
@@ -61,22 +63,23 @@ MSM_HD void te_tail(Xyzz& r, const Fe& A, const Fe& B, const Fe& C, const Fe& D,
 }
 
 // acc += (+/-) base   (7M).  -(X, Y) = (-X, Y): Y - X and Y + X trade places and 2dXY changes sign.
-template <class F>
+// SWAPPED = the caller has already exchanged ymx / ypx of a negated base (k_accumulate_coop does it with the LDS read
+// addresses); only the sign of 2dXY is left to apply.
+template <class F, bool SWAPPED = false>
 MSM_HD void te_madd(Xyzz& acc, const TeAffine& b, bool negate, const Modulus<F>& md) {
-  Fe ymx, ypx, t, td, ntd;
-  fe_sub(ymx, b.y, b.x, F::BIAS2_28);   // (p, 3p), limbs < 2^28 + 2^29
-  fe_add(ypx, b.y, b.x);                // < 2p,    limbs < 2^29
   const LaneMask neg = lane_mask(negate);
-  t = ymx;
-  fe_cmov(ymx, ypx, neg);
-  fe_cmov(ypx, t, neg);
+  Fe ymx = b.ymx, ypx = b.ypx, td, ntd;
+  if (!SWAPPED) {
+    fe_cmov(ymx, b.ypx, neg);
+    fe_cmov(ypx, b.ymx, neg);
+  }
   fe_neg(ntd, b.td, F::BIAS2_28);       // (p, 2p], limbs < 2^29
   td = b.td;
   fe_cmov(td, ntd, neg);
   Fe a1, b1, A, B, C, D;
   fe_sub(a1, acc.y, acc.x, F::BIAS2_28);   // (0, 4p), limbs < 2^28 + 2^29
   fe_add(b1, acc.y, acc.x);                // < 4p,    limbs < 2^29
-  fe_mul<F>(A, a1, ymx, md);               // 4p * 3p
+  fe_mul<F>(A, a1, ymx, md);               // 4p * p
   fe_mul<F>(B, b1, ypx, md);
   fe_mul<F>(C, acc.zzz, td, md);
   fe_dbl(D, acc.zz);                       // < 3p, limbs < 2^29
@@ -122,23 +125,25 @@ MSM_HD void te_map_prepare(Fe& u, Fe& v, Fe& w, Fe& den, const Affine& p, const 
   fe_mul<F>(den, v, w, md);
 }
 
-// With inv = 1/den:  X = FSC u w inv,  Y = (u - 1) v inv,  TD = 2d X Y; all canonical.
+// With inv = 1/den:  X = FSC u w inv,  Y = (u - 1) v inv;  the record is (Y - X, Y + X, 2d X Y), all canonical.
 template <class F>
 MSM_HD void te_map_finish(TeAffine& out, const Fe& u, const Fe& v, const Fe& w, const Fe& inv, const Modulus<F>& md) {
-  Fe t, c, one, um1;
+  Fe t, c, one, um1, X, Y;
   fe_set(one, F::ONE);
   fe_mul<F>(t, u, w, md);
   fe_mul<F>(t, t, inv, md);
   fe_set(c, Bls12_377_Te::FSC);
-  fe_mul<F>(out.x, t, c, md);
+  fe_mul<F>(X, t, c, md);
   fe_sub(um1, u, one, F::BIAS2_28);   // (0.5p, 3.5p), limbs < 2^28 + 2^29
   fe_mul<F>(t, um1, v, md);
-  fe_mul<F>(out.y, t, inv, md);
-  fe_mul<F>(t, out.x, out.y, md);
+  fe_mul<F>(Y, t, inv, md);
+  fe_mul<F>(t, X, Y, md);
   fe_set(c, Bls12_377_Te::K2D);
   fe_mul<F>(out.td, t, c, md);
-  fe_reduce<F>(out.x);
-  fe_reduce<F>(out.y);
+  fe_sub(out.ymx, Y, X, F::BIAS2_28);  // class M inputs: (0.5p, 3.5p), limbs < 2^28 + 2^29
+  fe_add(out.ypx, Y, X);               // < 3p, limbs < 2^29
+  fe_reduce<F>(out.ymx);
+  fe_reduce<F>(out.ypx);
   fe_reduce<F>(out.td);
 }
 

@@ -42,11 +42,12 @@ def uniform_scalars(n, top_limb, device, seed):
     bits = top_limb.bit_length()
     top = limbs[:, 3] & ((1 << bits) - 1)
     for _ in range(64):
+        # (torch.where, not boolean indexing: masked assignment drags torch's own rocPRIM partition kernels into the trace)
         bad = top >= top_limb
-        nbad = int(bad.sum().item())
-        if nbad == 0:
+        if int(bad.sum().item()) == 0:
             break
-        top[bad] = torch.randint(0, min(1 << bits, (1 << 63) - 1), (nbad,), dtype=torch.int64, device=device, generator=g)
+        fresh = torch.randint(0, min(1 << bits, (1 << 63) - 1), (n,), dtype=torch.int64, device=device, generator=g)
+        top = torch.where(bad, fresh, top)
     limbs[:, 3] = top
     return limbs.view(torch.uint8).reshape(n, 32)
 

@@ -59,7 +59,12 @@ def test_accumulate_kernel_isa(law):
     assert res["scratch"] <= 32 and res["occupancy"] >= 2 and res["vgprs"] <= 256
     assert 256 * 128 <= res["lds"] <= 80 * 1024     # the record slots of the quad-cooperative gather; two blocks per CU fit in 160 KB
     # the gathers are 16-B per lane and the pieces cross lanes through LDS
-    assert ops.count("ds_write_b128") >= 8 and ops.count("ds_read_b128") >= 7
+    assert ops.count("ds_write_b128") >= 8
+    if law == "sw":
+        assert ops.count("ds_read_b128") >= 7
+    else:
+        # Y - X and Y + X are read from each other's place for a negated base: 8-byte reads at a per-lane address
+        assert 2 * ops.count("ds_read2_b64") + ops.count("ds_read_b64") >= 14 and ops.count("v_cndmask_b32_e64") <= 24
     # selects must be the VOP3 form: v_cndmask_b32_e32 (mask implicit in VCC) issues at 22.9 cycles on gfx950 against 4.2 for
     # v_cndmask_b32_e64 (profiles/r02_ubench_valu_w4.txt); the sign handling of a mixed addition is 28-42 of them
     assert ops.count("v_cndmask_b32_e32") <= 2, ops.count("v_cndmask_b32_e32")
@@ -84,7 +89,7 @@ def test_partition_kernels_isa():
         lds = int(re.search(r"LDS Size \[bytes/block\]: (\d+)", blk).group(1))
         assert scratch == 0, (name, scratch)
         if "k_l1_scatter" in name or "k_pass_scatter" in name:
-            assert vgprs <= 128 and 64 * 1024 <= lds <= 120 * 1024, (name, vgprs, lds)
+            assert vgprs <= 128 and 64 * 1024 <= lds <= 150 * 1024, (name, vgprs, lds)
             seen += 1
     assert seen >= 5     # 4 instantiations of the level-1 scatter + the generic pass
     blob = open(os.path.join(ROOT, "2022-entries_amd", "libmi355msm.so"), "rb").read()
