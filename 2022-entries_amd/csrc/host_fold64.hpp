@@ -1,0 +1,377 @@
+// host_fold64.hpp -- the host tail of an MSM (window combine, chunk sums, normalisation) on 6 x 64-bit limbs.
+//
+// The device representation (fp28.hpp: 14 limbs of 28 bits, lazily reduced) is built for the GPU's 32x32 multiplier; run on a
+// CPU core it costs ~150 ns per field multiplication, and the ~260 sequential doublings of the Horner fold plus one
+// inversion were 0.4-0.5 ms per MSM -- half the wall time of a small MSM.  The same arithmetic on 64-bit limbs (CIOS with
+// 128-bit products, fully reduced) is ~4x faster.  This is the part every reference entry also leaves on the host
+// (SPK msm/pippenger.cuh:556-614, CMB yrrid-ff-ec/HostReduce.cpp:61-78); the formulas are the public EFD ones used in
+// curve.hpp / te.hpp, re-stated for canonical values.  G1 only (G2 keeps the generic path).
+//
+// Values are Montgomery residues with R = 2^384 -- exactly the ABI's representation, so results need no conversion.
+#pragma once
+#include <stdint.h>
+#include <string.h>
+
+#include "curve.hpp"
+
+namespace msm {
+
+struct F64 {
+  uint64_t l[6];
+};
+
+struct Fp64 {
+  uint64_t p[6];
+  uint64_t inv;      // -p^-1 mod 2^64
+  F64 one;           // R mod p
+  F64 from28;        // 2^376 mod p: mont_mul(v, from28) turns v = x * 2^392 (device radix) into x * 2^384
+  F64 two_d;         // twisted-Edwards 2d (BLS12-377 only), Montgomery form
+  F64 sqrt3, fsc_sqrt3;   // constants of the map back to short Weierstrass (te.hpp::te_to_sw)
+
+  static bool geq(const uint64_t* a, const uint64_t* b) {
+    for (int i = 5; i >= 0; i--)
+      if (a[i] != b[i]) return a[i] > b[i];
+    return true;
+  }
+  void cond_sub(uint64_t* t, uint64_t top) const {
+    if (top || geq(t, p)) {
+      unsigned __int128 br = 0;
+      for (int i = 0; i < 6; i++) {
+        const unsigned __int128 d = (unsigned __int128)t[i] - p[i] - (uint64_t)br;
+        t[i] = (uint64_t)d;
+        br = (d >> 64) & 1;
+      }
+    }
+  }
+  void add(F64& r, const F64& a, const F64& b) const {
+    unsigned __int128 c = 0;
+    uint64_t t[6];
+    for (int i = 0; i < 6; i++) {
+      c += (unsigned __int128)a.l[i] + b.l[i];
+      t[i] = (uint64_t)c;
+      c >>= 64;
+    }
+    cond_sub(t, (uint64_t)c);
+    memcpy(r.l, t, sizeof t);
+  }
+  void sub(F64& r, const F64& a, const F64& b) const {
+    unsigned __int128 br = 0;
+    uint64_t t[6];
+    for (int i = 0; i < 6; i++) {
+      const unsigned __int128 d = (unsigned __int128)a.l[i] - b.l[i] - (uint64_t)br;
+      t[i] = (uint64_t)d;
+      br = (d >> 64) & 1;
+    }
+    if (br) {
+      unsigned __int128 c = 0;
+      for (int i = 0; i < 6; i++) {
+        c += (unsigned __int128)t[i] + p[i];
+        t[i] = (uint64_t)c;
+        c >>= 64;
+      }
+    }
+    memcpy(r.l, t, sizeof t);
+  }
+  void dbl(F64& r, const F64& a) const { add(r, a, a); }
+  void neg(F64& r, const F64& a) const {
+    F64 z{};
+    sub(r, z, a);
+  }
+  bool is_zero(const F64& a) const { return (a.l[0] | a.l[1] | a.l[2] | a.l[3] | a.l[4] | a.l[5]) == 0; }
+  bool eq(const F64& a, const F64& b) const { return memcmp(a.l, b.l, sizeof a.l) == 0; }
+
+  // CIOS Montgomery multiplication (the algorithm of ARK ff montgomery_backend.rs:146-201), r = a b R^-1 mod p, canonical.
+  void mul(F64& r, const F64& a, const F64& b) const {
+    uint64_t t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < 6; i++) {
+      unsigned __int128 c = 0;
+      for (int j = 0; j < 6; j++) {
+        c += (unsigned __int128)a.l[j] * b.l[i] + t[j];
+        t[j] = (uint64_t)c;
+        c >>= 64;
+      }
+      c += t[6];
+      t[6] = (uint64_t)c;
+      t[7] = (uint64_t)(c >> 64);
+      const uint64_t m = t[0] * inv;
+      c = (unsigned __int128)m * p[0] + t[0];
+      c >>= 64;
+      for (int j = 1; j < 6; j++) {
+        c += (unsigned __int128)m * p[j] + t[j];
+        t[j - 1] = (uint64_t)c;
+        c >>= 64;
+      }
+      c += t[6];
+      t[5] = (uint64_t)c;
+      t[6] = t[7] + (uint64_t)(c >> 64);
+    }
+    cond_sub(t, t[6]);
+    memcpy(r.l, t, 48);
+  }
+  void sqr(F64& r, const F64& a) const { mul(r, a, a); }
+  // a^(p-2)
+  void invert(F64& r, const F64& a) const {
+    uint64_t e[6];
+    memcpy(e, p, sizeof e);
+    e[0] -= 2;   // p is odd and > 2: no borrow
+    F64 acc = one;
+    for (int i = 5; i >= 0; i--)
+      for (int b = 63; b >= 0; b--) {
+        sqr(acc, acc);
+        if ((e[i] >> b) & 1) mul(acc, acc, a);
+      }
+    r = acc;
+  }
+
+  // device field element (any bounded lazy value) -> F64
+  template <class F>
+  void from_device(F64& r, const Fe& a) const {
+    Fe t = a;
+    fe_reduce<F>(t);
+    uint32_t w[12];
+    fe_to_words(w, t);
+    F64 v;
+    for (int i = 0; i < 6; i++) v.l[i] = (uint64_t)w[2 * i] | ((uint64_t)w[2 * i + 1] << 32);
+    mul(r, v, from28);
+  }
+  void from_limbs28(F64& r, const uint32_t (&c)[NL]) const {   // a plain integer given as radix-2^28 limbs (< p)
+    Fe t;
+    fe_set(t, c);
+    uint32_t w[12];
+    fe_to_words(w, t);
+    for (int i = 0; i < 6; i++) r.l[i] = (uint64_t)w[2 * i] | ((uint64_t)w[2 * i + 1] << 32);
+  }
+
+  template <class F>
+  void init() {
+    Fe pp;
+    fe_set(pp, F::P);
+    uint32_t w[12];
+    fe_to_words(w, pp);
+    for (int i = 0; i < 6; i++) p[i] = (uint64_t)w[2 * i] | ((uint64_t)w[2 * i + 1] << 32);
+    uint64_t x = 1;   // Newton: x <- x (2 - p0 x) doubles the correct low bits
+    for (int i = 0; i < 7; i++) x *= 2 - p[0] * x;
+    inv = 0 - x;
+    // 2^k mod p by repeated doubling of 1
+    F64 v{};
+    v.l[0] = 1;
+    F64 p376{}, p384{}, p768{};
+    for (int k = 1; k <= 768; k++) {
+      add(v, v, v);
+      if (k == 376) p376 = v;
+      if (k == 384) p384 = v;
+      if (k == 768) p768 = v;
+    }
+    one = p384;
+    // from28 must be the Montgomery image of 2^-8, i.e. 2^-8 * 2^384 = 2^376
+    from28 = p376;
+    (void)p768;
+  }
+  // Montgomery image of a constant stored in the device representation (x * 2^392 mod p as radix-2^28 limbs)
+  template <class F>
+  void const_from_device(F64& r, const uint32_t (&c)[NL]) const {
+    Fe t;
+    fe_set(t, c);
+    from_device<F>(r, t);
+  }
+};
+
+struct Xyzz64 {
+  F64 x, y, zz, zzz;
+};
+
+// ---- short Weierstrass (a = 0), XYZZ: dbl-2008-s-1 and add-2008-s, canonical values ------------------------------------
+inline bool sw64_is_inf(const Fp64& f, const Xyzz64& a) { return f.is_zero(a.zz); }
+inline void sw64_set_inf(Xyzz64& a) { memset(&a, 0, sizeof a); }
+
+inline void sw64_dbl(const Fp64& f, Xyzz64& a) {
+  if (sw64_is_inf(f, a)) return;
+  F64 u, v, w, s, m, t, x3, y3;
+  f.dbl(u, a.y);
+  f.sqr(v, u);
+  f.mul(w, u, v);
+  f.mul(s, a.x, v);
+  f.sqr(m, a.x);
+  f.dbl(t, m);
+  f.add(m, t, m);            // 3 X^2
+  f.sqr(x3, m);
+  f.dbl(t, s);
+  f.sub(x3, x3, t);
+  f.sub(t, s, x3);
+  f.mul(y3, m, t);
+  f.mul(t, w, a.y);
+  f.sub(y3, y3, t);
+  a.x = x3;
+  a.y = y3;
+  f.mul(a.zz, v, a.zz);
+  f.mul(a.zzz, w, a.zzz);
+}
+
+inline void sw64_add(const Fp64& f, Xyzz64& a, const Xyzz64& b) {
+  if (sw64_is_inf(f, b)) return;
+  if (sw64_is_inf(f, a)) {
+    a = b;
+    return;
+  }
+  F64 u1, u2, s1, s2, P, R, PP, PPP, Q, t, x3, y3;
+  f.mul(u1, a.x, b.zz);
+  f.mul(u2, b.x, a.zz);
+  f.mul(s1, a.y, b.zzz);
+  f.mul(s2, b.y, a.zzz);
+  f.sub(P, u2, u1);
+  f.sub(R, s2, s1);
+  if (f.is_zero(P)) {
+    if (f.is_zero(R))
+      sw64_dbl(f, a);
+    else
+      sw64_set_inf(a);
+    return;
+  }
+  f.sqr(PP, P);
+  f.mul(PPP, P, PP);
+  f.mul(Q, u1, PP);
+  f.sqr(x3, R);
+  f.sub(x3, x3, PPP);
+  f.dbl(t, Q);
+  f.sub(x3, x3, t);
+  f.sub(t, Q, x3);
+  f.mul(y3, R, t);
+  f.mul(t, s1, PPP);
+  f.sub(y3, y3, t);
+  a.x = x3;
+  a.y = y3;
+  f.mul(t, a.zz, b.zz);
+  f.mul(a.zz, t, PP);
+  f.mul(t, a.zzz, b.zzz);
+  f.mul(a.zzz, t, PPP);
+}
+
+// XYZZ -> ABI Projective image, normalised: (x, y, 1) or (1, 1, 0)
+inline void sw64_to_abi(const Fp64& f, uint8_t* out, const Xyzz64& a) {
+  F64 x = f.one, y = f.one, z{};
+  if (!sw64_is_inf(f, a)) {
+    F64 t, ti, zzi, zzzi;
+    f.mul(t, a.zz, a.zzz);
+    f.invert(ti, t);
+    f.mul(zzi, ti, a.zzz);
+    f.mul(zzzi, ti, a.zz);
+    f.mul(x, a.x, zzi);
+    f.mul(y, a.y, zzzi);
+    z = f.one;
+  }
+  memcpy(out, x.l, 48);
+  memcpy(out + 48, y.l, 48);
+  memcpy(out + 96, z.l, 48);
+}
+
+template <class F>
+inline void xyzz64_from_device(const Fp64& f, Xyzz64& r, const Xyzz& a) {
+  f.from_device<F>(r.x, a.x);
+  f.from_device<F>(r.y, a.y);
+  f.from_device<F>(r.zz, a.zz);
+  f.from_device<F>(r.zzz, a.zzz);
+}
+
+// result = sum_w 2^(c w) sums[w]   (Horner, high to low)
+template <class F>
+inline void fold_windows64(const Fp64& f, Xyzz64& acc, const Xyzz* sums, int windows, int c) {
+  sw64_set_inf(acc);
+  for (int w = windows - 1; w >= 0; w--) {
+    for (int i = 0; i < c; i++) sw64_dbl(f, acc);
+    Xyzz64 s;
+    xyzz64_from_device<F>(f, s, sums[w]);
+    sw64_add(f, acc, s);
+  }
+}
+
+// ---- twisted Edwards a = -1, extended coordinates (x = X, y = Y, zz = Z, zzz = T), as te.hpp ----------------------------
+// add-2008-hwcd-3 (unified) and the dedicated doubling dbl-2008-hwcd (4M + 4S).  false = Z3 = 0: vanishing denominator.
+inline bool te64_add(const Fp64& f, Xyzz64& a, const Xyzz64& b) {
+  F64 a1, a2, b1, b2, A, B, C, D, E, Fv, G, H, t;
+  f.sub(a1, a.y, a.x);
+  f.sub(a2, b.y, b.x);
+  f.add(b1, a.y, a.x);
+  f.add(b2, b.y, b.x);
+  f.mul(A, a1, a2);
+  f.mul(B, b1, b2);
+  f.mul(t, b.zzz, f.two_d);
+  f.mul(C, a.zzz, t);
+  f.mul(t, a.zz, b.zz);
+  f.dbl(D, t);
+  f.sub(E, B, A);
+  f.sub(Fv, D, C);
+  f.add(G, D, C);
+  f.add(H, B, A);
+  f.mul(a.x, E, Fv);
+  f.mul(a.y, G, H);
+  f.mul(a.zzz, E, H);
+  f.mul(a.zz, Fv, G);
+  return !f.is_zero(a.zz);
+}
+inline bool te64_dbl(const Fp64& f, Xyzz64& a) {
+  F64 A, B, C, D, E, G, Fv, H, t;
+  f.sqr(A, a.x);
+  f.sqr(B, a.y);
+  f.sqr(t, a.zz);
+  f.dbl(C, t);
+  f.neg(D, A);                 // a = -1
+  f.add(t, a.x, a.y);
+  f.sqr(E, t);
+  f.sub(E, E, A);
+  f.sub(E, E, B);
+  f.add(G, D, B);
+  f.sub(Fv, G, C);
+  f.sub(H, D, B);
+  f.mul(a.x, E, Fv);
+  f.mul(a.y, G, H);
+  f.mul(a.zzz, E, H);
+  f.mul(a.zz, Fv, G);
+  return !f.is_zero(a.zz);
+}
+
+// Horner on the Edwards image, then back to short Weierstrass (te.hpp::te_to_sw), as an XYZZ64 affine point.
+// false: a vanishing denominator was hit (possible only off the odd-order subgroup) -- the caller repeats on XYZZ.
+template <class F>
+inline bool fold_windows_te64(const Fp64& f, Xyzz64& out, const Xyzz* sums, int windows, int c) {
+  Xyzz64 acc{};
+  acc.y = f.one;
+  acc.zz = f.one;   // identity (0, 1, 1, 0)
+  for (int w = windows - 1; w >= 0; w--) {
+    if (w != windows - 1)
+      for (int i = 0; i < c; i++)
+        if (!te64_dbl(f, acc)) return false;
+    Xyzz64 s;
+    xyzz64_from_device<F>(f, s, sums[w]);
+    if (f.is_zero(s.zz)) return false;
+    if (!te64_add(f, acc, s)) return false;
+  }
+  // (0, 1) -> infinity, (0, -1) -> the 2-torsion point (-1, 0); otherwise u = (Z + Y)/(Z - Y), v = FSC u Z / X
+  if (f.is_zero(acc.x)) {
+    if (f.eq(acc.y, acc.zz)) {
+      sw64_set_inf(out);
+    } else {
+      f.neg(out.x, f.one);
+      memset(&out.y, 0, sizeof out.y);
+      out.zz = f.one;
+      out.zzz = f.one;
+    }
+    return true;
+  }
+  F64 n, dn, den, inv, t;
+  f.add(n, acc.zz, acc.y);
+  f.sub(dn, acc.zz, acc.y);
+  f.mul(den, dn, acc.x);
+  f.invert(inv, den);
+  f.mul(t, n, acc.x);
+  f.mul(t, t, inv);                 // u
+  f.mul(t, t, f.sqrt3);
+  f.sub(out.x, t, f.one);
+  f.mul(t, n, acc.zz);
+  f.mul(t, t, inv);                 // u Z / X
+  f.mul(out.y, t, f.fsc_sqrt3);
+  out.zz = f.one;
+  out.zzz = f.one;
+  return true;
+}
+
+}  // namespace msm

@@ -306,3 +306,111 @@ int ht_te_add_chains(const uint8_t* pts, size_t stride, size_t na, size_t nb, in
   return te_finish_host(out, a, md);
 }
 }
+
+// ---- the 64-bit host tail (host_fold64.hpp) against the generic arithmetic ------------------------------------------------
+#include <type_traits>
+
+#include "host_fold64.hpp"
+
+template <class F>
+static const Fp64& test_fp64() {
+  static Fp64 f = [] {
+    Fp64 g{};
+    g.init<F>();
+    if (F::P[0] == 1) {   // BLS12-377: the twisted-Edwards constants
+      g.const_from_device<F>(g.two_d, Bls12_377_Te::K2D);
+      g.const_from_device<F>(g.sqrt3, Bls12_377_Te::SQRT3);
+      g.const_from_device<F>(g.fsc_sqrt3, Bls12_377_Te::FSC_SQRT3);
+    }
+    return g;
+  }();
+  return f;
+}
+
+// field: out = a * b (ABI Montgomery images in and out), through Fp64::mul / add / sub / invert; op selects
+template <class F>
+static int t_f64_op(int op, const uint8_t* a, const uint8_t* b, uint8_t* out) {
+  const Fp64& f = test_fp64<F>();
+  F64 x, y, z;
+  memcpy(x.l, a, 48);
+  memcpy(y.l, b, 48);
+  switch (op) {
+    case 0: f.mul(z, x, y); break;
+    case 1: f.add(z, x, y); break;
+    case 2: f.sub(z, x, y); break;
+    case 3: f.invert(z, x); break;
+    default: return 1;
+  }
+  memcpy(out, z.l, 48);
+  return 0;
+}
+extern "C" int ht_f64_op(int curve, int op, const uint8_t* a, const uint8_t* b, uint8_t* out) {
+  return curve == 1 ? t_f64_op<Bls12_381_Fq>(op, a, b, out) : t_f64_op<Bls12_377_Fq>(op, a, b, out);
+}
+
+// Window sums S_w = k_w * P_w (affine images + 64-bit multipliers) folded with window size c, both ways; the two Projective
+// images go to out_generic / out_fold64.  te = 1 (BLS12-377 only): the sums live on the twisted-Edwards image.
+// Returns 0, or 2 when an Edwards addition hit a vanishing denominator (both implementations must agree on that too).
+template <class C>
+static int t_fold_both(const uint8_t* pts, size_t stride, const uint64_t* mult, int windows, int c, int te, uint8_t* out_generic,
+                       uint8_t* out_fold64) {
+  using E = typename C::E;
+  using F = typename E::Fld;
+  typename E::Md md;
+  const Fp64& f = test_fp64<F>();
+  Xyzz sums[64];
+  if (windows > 64) return 1;
+  for (int w = 0; w < windows; w++) {
+    Affine a;
+    const bool inf = affine_from_abi<E>(a, pts + (size_t)w * stride, md);
+    if (te) {
+      if constexpr (std::is_same<F, Bls12_377_Fq>::value) {
+        te_set_identity<F>(sums[w]);
+        if (!inf) {
+          TeAffine t;
+          if (!te_map_host(t, pts + (size_t)w * stride, md)) return 1;
+          for (int bit = 63; bit >= 0; bit--) {
+            te_dbl<F>(sums[w], md);
+            if ((mult[w] >> bit) & 1) te_madd<F>(sums[w], t, false, md);
+          }
+        }
+      } else {
+        return 1;
+      }
+    } else {
+      xyzz_set_inf<E>(sums[w]);
+      if (!inf) {
+        const uint64_t k[4] = {mult[w], 0, 0, 0};
+        xyzz_mul_u64x4<E>(sums[w], a, k, md);
+      }
+    }
+  }
+  Xyzz g;
+  Xyzz64 h;
+  bool ok_g = true, ok_h = true;
+  if (te) {
+    ok_g = fold_windows_te<F>(g, sums, windows, c, md);
+    ok_h = fold_windows_te64<F>(f, h, sums, windows, c);
+  } else {
+    fold_windows<E>(g, sums, windows, c, md);
+    fold_windows64<F>(f, h, sums, windows, c);
+  }
+  if (ok_g != ok_h) return 3;
+  if (!ok_g) return 2;
+  xyzz_to_projective_abi<E>(out_generic, g, md);
+  sw64_to_abi(f, out_fold64, h);
+  // the chunk sum as well: h + h against the generic doubling
+  Xyzz64 hh = h;
+  sw64_add(f, hh, h);
+  Xyzz gg = g;
+  xyzz_add<E>(gg, g, md);
+  uint8_t b1[144], b2[144];
+  xyzz_to_projective_abi<E>(b1, gg, md);
+  sw64_to_abi(f, b2, hh);
+  return memcmp(b1, b2, 144) == 0 ? 0 : 4;
+}
+extern "C" int ht_fold_both(int curve, const uint8_t* pts, size_t stride, const uint64_t* mult, int windows, int c, int te,
+                            uint8_t* out_generic, uint8_t* out_fold64) {
+  if (curve == 1) return te ? 1 : t_fold_both<Bls12_381_G1>(pts, stride, mult, windows, c, 0, out_generic, out_fold64);
+  return t_fold_both<Bls12_377_G1>(pts, stride, mult, windows, c, te, out_generic, out_fold64);
+}

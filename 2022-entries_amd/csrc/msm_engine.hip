@@ -26,6 +26,7 @@
 
 #include "../../include/mi355_msm.h"
 #include "host_curve.hpp"
+#include "host_fold64.hpp"
 #include "launch.hpp"
 
 namespace {
@@ -396,32 +397,56 @@ void set_bases_device(mi355_msm_ctx* ctx, const void* d_affine, size_t n, size_t
   ctx->nbases = n;
 }
 
-// result = sum_w 2^(c*w) * sums[w] on the twisted-Edwards image, mapped back to short-Weierstrass XYZZ.
-// false: an addition hit a vanishing denominator (possible only off the odd-order subgroup).
-inline bool fold_windows_te(Xyzz& out, const Xyzz* sums, int windows, int c, const Modulus<Bls12_377_Fq>& md) {
-  using F = Bls12_377_Fq;
-  Xyzz acc;
-  te_set_identity<F>(acc);
-  for (int w = windows - 1; w >= 0; w--) {
-    if (w != windows - 1)
-      for (int i = 0; i < c; i++) {
-        te_dbl<F>(acc, md);
-        if (te_failed<F>(acc)) return false;
-      }
-    if (te_failed<F>(sums[w])) return false;
-    te_add<F>(acc, sums[w], md);
-    if (te_failed<F>(acc)) return false;
-  }
-  te_to_sw<F>(out, acc, md);
-  return true;
+// ---- the host tail (window fold, chunk sums, normalisation) -----------------------------------------------------------
+// G1: on 64-bit limbs (host_fold64.hpp, ~4x faster than the device representation run on a CPU core); G2: the generic code.
+template <class F>
+const Fp64& fp64_of() {
+  static const Fp64 ctx = [] {
+    Fp64 f{};
+    f.init<F>();
+    if constexpr (std::is_same_v<F, Bls12_377_Fq>) {
+      f.const_from_device<F>(f.two_d, Bls12_377_Te::K2D);
+      f.const_from_device<F>(f.sqrt3, Bls12_377_Te::SQRT3);
+      f.const_from_device<F>(f.fsc_sqrt3, Bls12_377_Te::FSC_SQRT3);
+    }
+    return f;
+  }();
+  return ctx;
 }
+
+template <class E>
+struct HostTail {   // generic (G2): the device representation, host_curve.hpp
+  using Pt = XyzzT<typename E::T>;
+  static void set_inf(Pt& a) { xyzz_set_inf<E>(a); }
+  static void add(Pt& a, const Pt& b) {
+    typename E::Md md;
+    xyzz_add<E>(a, b, md);
+  }
+  static void fold(Pt& out, const Pt* sums, int windows, int c) {
+    typename E::Md md;
+    fold_windows<E>(out, sums, windows, c, md);
+  }
+  static void to_abi(uint8_t* out, const Pt& a) {
+    typename E::Md md;
+    xyzz_to_projective_abi<E>(out, a, md);
+  }
+};
+template <class F>
+struct HostTail<FpEl<F>> {
+  using Pt = Xyzz64;
+  static void set_inf(Pt& a) { sw64_set_inf(a); }
+  static void add(Pt& a, const Pt& b) { sw64_add(fp64_of<F>(), a, b); }
+  static void fold(Pt& out, const Xyzz* sums, int windows, int c) { fold_windows64<F>(fp64_of<F>(), out, sums, windows, c); }
+  static bool fold_te(Pt& out, const Xyzz* sums, int windows, int c) { return fold_windows_te64<F>(fp64_of<F>(), out, sums, windows, c); }
+  static void to_abi(uint8_t* out, const Pt& a) { sw64_to_abi(fp64_of<F>(), out, a); }
+};
 
 // One chunk of one batch: device scalars [0, n) against bases [base0, base0 + n).  Leaves the folded chunk sum in `out`.
 // TE = true runs the twisted-Edwards kernels (BLS12-377 G1 contexts whose bases all have an image) and returns false when
 // an addition reported a vanishing denominator: the caller then repeats the chunk with TE = false.
 template <class C, bool TE>
 bool run_chunk_impl(mi355_msm_ctx* ctx, const uint32_t* d_scalars, size_t base0, size_t n, hipStream_t st,
-                    XyzzT<typename C::E::T>& out, const std::function<void()>* while_gpu_busy) {
+                    typename HostTail<typename C::E>::Pt& out, const std::function<void()>* while_gpu_busy) {
   using E = typename C::E;
   using El = typename E::T;
   using XyzzDev = XyzzDevT<El>;
@@ -553,10 +578,12 @@ bool run_chunk_impl(mi355_msm_ctx* ctx, const uint32_t* d_scalars, size_t base0,
   const XyzzDev* hs = reinterpret_cast<const XyzzDev*>(ctx->pinned);
   for (uint32_t w = 0; w < p.bucket_windows; w++) sums[w] = hs[w].p;
   bool ok = true;
+  const auto t_fold = std::chrono::steady_clock::now();
   if constexpr (TE)
-    ok = ctx->h_flags[1] == 0 && fold_windows_te(out, sums.data(), (int)p.bucket_windows, (int)p.c, md);
+    ok = ctx->h_flags[1] == 0 && HostTail<E>::fold_te(out, sums.data(), (int)p.bucket_windows, (int)p.c);
   else
-    fold_windows<E>(out, sums.data(), (int)p.bucket_windows, (int)p.c, md);
+    HostTail<E>::fold(out, sums.data(), (int)p.bucket_windows, (int)p.c);
+  ctx->last_ms[MI355_T_HOST_FOLD] += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_fold).count();
 
   float ms = 0;
   for (int s = 0; s < 5; s++) {
@@ -578,7 +605,7 @@ bool run_chunk_impl(mi355_msm_ctx* ctx, const uint32_t* d_scalars, size_t base0,
 
 template <class C>
 void run_chunk(mi355_msm_ctx* ctx, const uint32_t* d_scalars, size_t base0, size_t n, hipStream_t st,
-               XyzzT<typename C::E::T>& out, const std::function<void()>* while_gpu_busy = nullptr) {
+               typename HostTail<typename C::E>::Pt& out, const std::function<void()>* while_gpu_busy = nullptr) {
   if constexpr (std::is_same_v<C, Bls12_377_G1>) {
     if (ctx->te_active) {
       if (run_chunk_impl<C, true>(ctx, d_scalars, base0, n, st, out, while_gpu_busy)) {
@@ -649,8 +676,8 @@ void run_device_t(mi355_msm_ctx* ctx, uint8_t* out, const uint32_t* d_scalars, s
       hb->copy(0);
   }
   for (size_t b = 0; b < batches; b++) {
-    Xyzz total;
-    xyzz_set_inf<E>(total);
+    typename HostTail<E>::Pt total;
+    HostTail<E>::set_inf(total);
     const bool split = head && b == 0;
     if (hb && n) HIP_OK(hipStreamWaitEvent(st, split ? hb->head : hb->ready[b & 1], 0));
     bool rest_issued = !split, rest_awaited = !split, prefetched = false;
@@ -674,7 +701,7 @@ void run_device_t(mi355_msm_ctx* ctx, uint8_t* out, const uint32_t* d_scalars, s
         HIP_OK(hipStreamWaitEvent(st, hb->ready[0], 0));
         rest_awaited = true;
       }
-      Xyzz part;
+      typename HostTail<E>::Pt part;
       const std::function<void()>* hook = (!rest_issued) ? &rest_of_first : ((last && !prefetched) ? &prefetch : nullptr);
       try {
         run_chunk<C>(ctx, d_scalars + (b * dev_batch_pairs + off) * 8, off, cn, st, part, hook);
@@ -692,12 +719,12 @@ void run_device_t(mi355_msm_ctx* ctx, uint8_t* out, const uint32_t* d_scalars, s
         ctx->fitted_chunk = cn;
         ctx->fitted_tables = tables_now;
       }
-      xyzz_add<E>(total, part, md);
+      HostTail<E>::add(total, part);
       off += cn;
     }
     if (!prefetched) prefetch();   // n == 0
     const auto t0 = std::chrono::steady_clock::now();
-    xyzz_to_projective_abi<E>(out + b * out_bytes, total, md);
+    HostTail<E>::to_abi(out + b * out_bytes, total);
     ctx->last_ms[MI355_T_HOST_FOLD] += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
   }
 }

@@ -188,4 +188,26 @@ MSM_HD void te_to_sw(Xyzz& out, const Xyzz& a, const Modulus<F>& md) {
   out.zzz = one;
 }
 
+// result = sum_w 2^(c*w) * sums[w] on the twisted-Edwards image, mapped back to short-Weierstrass XYZZ (generic arithmetic;
+// the engine's host tail uses the 64-bit twin in host_fold64.hpp, tests/test_fold64_host.py compares the two).
+// false: an addition hit a vanishing denominator (possible only off the odd-order subgroup).
+template <class F>
+MSM_HD bool fold_windows_te(Xyzz& out, const Xyzz* sums, int windows, int c, const Modulus<F>& md) {
+  Xyzz acc;
+  te_set_identity<F>(acc);
+  for (int w = windows - 1; w >= 0; w--) {
+    if (w != windows - 1)
+      for (int i = 0; i < c; i++) {
+        te_dbl<F>(acc, md);
+        if (te_failed<F>(acc)) return false;
+      }
+    if (te_failed<F>(sums[w])) return false;
+    te_add<F>(acc, sums[w], md);
+    if (te_failed<F>(acc)) return false;
+  }
+  te_to_sw<F>(out, acc, md);
+  return true;
+}
+
+
 }  // namespace msm

@@ -22,8 +22,8 @@ __global__ void __launch_bounds__(256, 2) kmadd(const Fe* A, Xyzz* C, int iters)
     for (int k = 0; k < iters; k++) SwLaw<FpEl<F>>::madd(acc, p, (k & 1) != 0, false, md);
   } else {
     TeAffine p;
-    p.x = A[2 * i];
-    p.y = A[2 * i + 1];
+    p.ymx = A[2 * i];
+    p.ypx = A[2 * i + 1];
     p.td = A[2 * i];
     te_set_identity<F>(acc);
     for (int k = 0; k < iters; k++) TeLaw<F>::madd(acc, p, (k & 1) != 0, false, md);
