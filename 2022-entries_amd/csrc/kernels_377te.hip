@@ -18,7 +18,7 @@ hipError_t LaunchTe::convert(const AffineDev* in, const uint8_t* inf, uint32_t n
 
 hipError_t LaunchTe::accumulate(const uint2* entries, const uint32_t* n_real, uint32_t K,
                                 const TeAffineDev* bases, SegOut out, uint32_t nlanes, uint32_t* flags, hipStream_t st) {
-  hipLaunchKernelGGL((k_accumulate_coop<G>), dim3(te_blocks(nlanes)), dim3(256), 0, st, entries, n_real, K, bases, out, nlanes, flags);
+  hipLaunchKernelGGL((k_accumulate_glds<G>), dim3(te_blocks(nlanes)), dim3(256), 0, st, entries, n_real, K, bases, out, nlanes, flags);
   return hipGetLastError();
 }
 

@@ -20,14 +20,16 @@ hipError_t Launch<E>::convert_bases(const uint8_t* in, size_t stride, uint32_t n
 template <class E>
 hipError_t Launch<E>::accumulate(const uint2* entries, const uint32_t* n_real, uint32_t K,
                                  const AffineDevT<El>* bases, SegOutT<El> out, uint32_t nlanes, hipStream_t st) {
-  // G1 (128-B records): quad-cooperative gathers (-2.7 % on BLS12-381, tools/ab_bench.sh); G2 keeps one lane per record
-  if constexpr (sizeof(AffineDevT<El>) == 128) {
-    hipLaunchKernelGGL((k_accumulate_coop<SwLaw<E>>), dim3(launch_blocks(nlanes)), dim3(256), 0, st, entries, n_real, K, bases, out,
-                       nlanes, (uint32_t*)nullptr);
-    return hipGetLastError();
-  }
-  hipLaunchKernelGGL((k_accumulate<SwLaw<E>>), dim3(launch_blocks(nlanes)), dim3(256), 0, st, entries, n_real, K, bases, out, nlanes,
-                     (uint32_t*)nullptr);
+  // MSM_GATHER = 0 builds the one-lane-per-record walk instead (A/B: profiles/r02_ab_gather.txt)
+#ifndef MSM_GATHER
+#define MSM_GATHER 2
+#endif
+  if constexpr (MSM_GATHER == 2)
+    hipLaunchKernelGGL((k_accumulate_glds<SwLaw<E>>), dim3(launch_blocks(nlanes)), dim3(256), 0, st, entries, n_real, K, bases, out, nlanes,
+                       (uint32_t*)nullptr);
+  else
+    hipLaunchKernelGGL((k_accumulate<SwLaw<E>>), dim3(launch_blocks(nlanes)), dim3(256), 0, st, entries, n_real, K, bases, out, nlanes,
+                       (uint32_t*)nullptr);
   return hipGetLastError();
 }
 

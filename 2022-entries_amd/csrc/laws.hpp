@@ -14,30 +14,34 @@
 
 namespace msm {
 
-// 14 limbs out of an 8-byte aligned run of (LDS) bytes, as 7 two-word reads
-MSM_HD void copy_fe_words(Fe& r, const unsigned char* src) {
-  const uint2* s2 = reinterpret_cast<const uint2*>(src);
-#pragma unroll
-  for (int i = 0; i < NL / 2; i++) {
-    const uint2 v = s2[i];
-    r.v[2 * i] = v.x;
-    r.v[2 * i + 1] = v.y;
-  }
-}
-// a whole record out of a 16-byte aligned run of bytes, as 16-byte reads
+// a whole record whose 64-B sectors lie `rs` bytes apart (k_accumulate_glds), as 16-byte reads
 template <class B>
-MSM_HD void copy_record_words(B& p, const unsigned char* src) {
+MSM_HD void copy_record_sectors(B& p, const unsigned char* rec, int rs) {
   constexpr int WORDS = (int)(sizeof(B) / 4), PIECES = (WORDS + 3) / 4;
-  const uint4* s4 = reinterpret_cast<const uint4*>(src);
   uint32_t* dst = reinterpret_cast<uint32_t*>(&p);
 #pragma unroll
   for (int q = 0; q < PIECES; q++) {
-    const uint4 v = s4[q];
+    const uint4 v = *reinterpret_cast<const uint4*>(rec + (q / 4) * rs + (q % 4) * 16);
     if (4 * q < WORDS) dst[4 * q] = v.x;
     if (4 * q + 1 < WORDS) dst[4 * q + 1] = v.y;
     if (4 * q + 2 < WORDS) dst[4 * q + 2] = v.z;
     if (4 * q + 3 < WORDS) dst[4 * q + 3] = v.w;
   }
+}
+// one field element at the start of a 64-B sector
+MSM_HD void copy_fe_sector(Fe& r, const unsigned char* src) {
+  const uint4* s4 = reinterpret_cast<const uint4*>(src);
+#pragma unroll
+  for (int q = 0; q < 3; q++) {
+    const uint4 v = s4[q];
+    r.v[4 * q] = v.x;
+    r.v[4 * q + 1] = v.y;
+    r.v[4 * q + 2] = v.z;
+    r.v[4 * q + 3] = v.w;
+  }
+  const uint2 w = *reinterpret_cast<const uint2*>(src + 48);
+  r.v[12] = w.x;
+  r.v[13] = w.y;
 }
 
 template <class E_>
@@ -50,14 +54,12 @@ struct SwLaw {
   static constexpr bool CHECKS = false;
   static constexpr int ACC_WAVES = E::ACC_WAVES;
   static constexpr bool PREFETCH_BASE = E::PREFETCH_BASE;
-  // quad-cooperative gathers (k_accumulate_coop) for 128-B records: slots padded to 144 B against LDS bank conflicts
-  static constexpr bool COOP_GATHER = sizeof(BaseDev) == 128;
-  static constexpr int COOP_LDS_STRIDE = 144;
+  static MSM_HD Base from_dev(const BaseDev& d) { return d.p; }
   static MSM_HD void set_identity(XyzzT<T>& r) { xyzz_set_inf<E>(r); }
   static MSM_HD void begin_run(XyzzT<T>&) {}   // XYZZ: the `fresh` flag makes the first madd a copy
   static MSM_HD void madd(XyzzT<T>& acc, const Base& b, bool negate, bool fresh, const Md& md) { xyzz_madd<E>(acc, b, negate, fresh, md); }
-  // k_accumulate_coop: a lane's record as it lies in its LDS slot -> registers; madd_loaded consumes what load_record produced
-  static MSM_HD void load_record(Base& p, const unsigned char* slot, bool /*negate*/) { copy_record_words(p, slot); }
+  // k_accumulate_glds: a lane's record as it lies in LDS (sector c at rec + c * rs) -> registers; madd_loaded consumes it
+  static MSM_HD void load_sectors(Base& p, const unsigned char* rec, int rs, bool /*negate*/) { copy_record_sectors(p, rec, rs); }
   static MSM_HD void madd_loaded(XyzzT<T>& acc, const Base& b, bool negate, bool fresh, const Md& md) { xyzz_madd<E>(acc, b, negate, fresh, md); }
   static MSM_HD void add(XyzzT<T>& acc, const XyzzT<T>& b, const Md& md) { xyzz_add<E>(acc, b, md); }
   static MSM_HD void mul_pow2(XyzzT<T>& acc, uint32_t k, const Md& md) {
@@ -83,23 +85,20 @@ struct TeLaw {
 #endif
   static constexpr int ACC_WAVES = TE_ACC_WAVES;
   static constexpr bool PREFETCH_BASE = TE_PREFETCH;
-  // quad-cooperative gathers (k_accumulate_coop): a 192-B record slot padded to 208 B so that the lanes' 16-B reads spread over
-  // the LDS banks (a 192-B stride would put every fourth lane on the same banks)
-  static constexpr bool COOP_GATHER = true;
-  static constexpr int COOP_LDS_STRIDE = 208;
+  static MSM_HD Base from_dev(const BaseDev& d) { return d.get(); }
   static MSM_HD void set_identity(Xyzz& r) { te_set_identity<F>(r); }
   // A run's first element is added onto the identity through the same 7M formula: a cheaper "copy" branch would be taken by
   // some lane of a wave at most positions (runs are ~64 entries long), so the whole wave would pay for both paths.
   // The accumulator is reset in begin_run (a handful of moves under the run-change branch the walk has anyway).
   static MSM_HD void begin_run(Xyzz& acc) { te_set_identity<F>(acc); }
   static MSM_HD void madd(Xyzz& acc, const Base& b, bool negate, bool /*fresh*/, const Md& md) { te_madd<F>(acc, b, negate, md); }
-  // A negated base reads Y - X and Y + X from each other's place: two LDS addresses instead of 28 selects per addition
-  // (the 56-byte fields are 8-byte aligned in the slot: 7 x ds_read_b64 each).
-  static MSM_HD void load_record(Base& p, const unsigned char* slot, bool negate) {
-    const uint32_t o0 = negate ? (uint32_t)sizeof(Fe) : 0u, o1 = (uint32_t)sizeof(Fe) - o0;
-    copy_fe_words(p.ymx, slot + o0);
-    copy_fe_words(p.ypx, slot + o1);
-    copy_fe_words(p.td, slot + 2 * sizeof(Fe));
+  // k_accumulate_glds: the device record keeps one field per 64-B sector, so a negated base reads Y - X and Y + X from each
+  // other's SECTOR: two LDS addresses instead of 28 selects per addition
+  static MSM_HD void load_sectors(Base& p, const unsigned char* rec, int rs, bool negate) {
+    const int o0 = negate ? rs : 0, o1 = rs - o0;
+    copy_fe_sector(p.ymx, rec + o0);
+    copy_fe_sector(p.ypx, rec + o1);
+    copy_fe_sector(p.td, rec + 2 * rs);
   }
   static MSM_HD void madd_loaded(Xyzz& acc, const Base& b, bool negate, bool /*fresh*/, const Md& md) { te_madd<F, true>(acc, b, negate, md); }
   // Z = 0 never occurs in a valid point: it marks an empty (zero-filled) bucket, which adds nothing.

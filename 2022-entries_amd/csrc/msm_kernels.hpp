@@ -2,7 +2,7 @@
 //
 //   k_convert_bases   arkworks Affine image (stride bytes, R = 2^384)  ->  device Affine (112 B, radix 2^28, R = 2^392)
 //   (partition.hpp)   256-bit scalars -> signed c-bit digits -> (bucket key, base index | sign) entries grouped by key
-//   k_accumulate      sorted-range walk: each lane owns K consecutive sorted entries and mixed-adds their
+//   k_accumulate[_glds] sorted-range walk: each lane owns K consecutive sorted entries and mixed-adds their
 //                     bases; finished buckets are stored once, run fragments that cross a lane boundary
 //                     go to per-lane head/tail slots
 //   k_segreduce       merges the slot fragments (same walk, full XYZZ add), recursively
@@ -117,7 +117,7 @@ __global__ void __launch_bounds__(256, G::ACC_WAVES) k_accumulate(const uint2* _
   if (end - beg > 1) ent_n = entries[beg + 1];
   // (G::PREFETCH_BASE = false -- G2, whose accumulator alone is 112 VGPRs -- gathers the base at its point of use instead)
   typename G::Base p_c;
-  if (G::PREFETCH_BASE) p_c = bases[ent_c.x & IDX_MASK].p;
+  if (G::PREFETCH_BASE) p_c = G::from_dev(bases[ent_c.x & IDX_MASK]);
 
   uint32_t cur = KEY_NONE;
   bool first = true, fresh = true, bad = false;
@@ -125,10 +125,10 @@ __global__ void __launch_bounds__(256, G::ACC_WAVES) k_accumulate(const uint2* _
   G::set_identity(acc);
   for (uint32_t e = beg; e < end; e++) {
     const uint32_t key = ent_c.y, val = ent_c.x;
-    if (!G::PREFETCH_BASE) p_c = bases[val & IDX_MASK].p;
+    if (!G::PREFETCH_BASE) p_c = G::from_dev(bases[val & IDX_MASK]);
     const typename G::Base p = p_c;
     ent_c = ent_n;
-    if (G::PREFETCH_BASE && end - e > 1) p_c = bases[ent_c.x & IDX_MASK].p;
+    if (G::PREFETCH_BASE && end - e > 1) p_c = G::from_dev(bases[ent_c.x & IDX_MASK]);
     if (end - e > 2) ent_n = entries[e + 2];
     if (key != cur) {
       if (cur != KEY_NONE) {
@@ -147,34 +147,47 @@ __global__ void __launch_bounds__(256, G::ACC_WAVES) k_accumulate(const uint2* _
   if (G::CHECKS && bad) flags[1] = 1;
 }
 
-// The same walk with QUAD-COOPERATIVE gathers (laws with COOP_GATHER).  tools/ubench_gather.hip: when every lane of a wave
-// loads 16 B from its own random record, the texture-address path resolves ~80 G lane-loads/s chip-wide -- 1.3 TB/s, 6.6 G
-// 192-B records/s, which is where a one-lane-per-record gather of twisted-Edwards bases stalls (VALU 72 % busy).  When the four
-// lanes of a quad fetch their four records TOGETHER, lane l taking bytes [16 l, 16 l + 16) of every 64-B sector, one
-// wave-instruction touches 16 lines instead of 64 and the same chip gathers 24 G records/s (4.7 TB/s).  The pieces cross lanes
-// through LDS: every lane writes the 4 x SECT pieces it fetched into the quad's four record slots and reads its own record
-// back as one contiguous run (same-wave LDS traffic is ordered, so no barrier; slots are padded against bank conflicts).
-// All lanes of a wave stay in the loop until the whole wave is done, because the quad needs all four of them.
+// The same walk with QUAD-COOPERATIVE gathers done by LDS-DMA (`global_load_lds_dwordx4`: global -> LDS, no VGPR in between).
+// tools/ubench_gather.hip: when every lane of a wave loads 16 B from its own random record, the texture-address path resolves
+// ~80 G lane-loads/s chip-wide -- 1.3 TB/s, 6.6 G 192-B records/s, which is where a one-lane-per-record gather of twisted-Edwards
+// bases stalls (VALU 72 % busy).  When the four lanes of a quad fetch their four records TOGETHER, lane l taking bytes
+// [16 l, 16 l + 16) of every 64-B sector, one wave-instruction touches 16 lines instead of 64 and the same chip gathers 24 G
+// records/s (4.7 TB/s).  Round 1 staged the pieces in 32-48 VGPRs and handed them over with 8-12 ds_write_b128 per addition; G2
+// could not afford the registers at all (256 VGPRs + 246 AGPRs: it gathered at the point of use and stalled ~2 us per
+// addition).  With LDS-DMA (profiles/r02_ab_gather.txt: -0.7 % / -0.4 % / -3.0 % on the three curves) a wave instruction
+// (record i of every quad, sector c) lands as
+// ONE lane-linear kilobyte in LDS -- lane l = 4 quad + sub wrote the 16-B piece `sub` of sector c, so the 64 bytes of
+// quad q's sector lie contiguous at offset 64 q -- and a lane reads its own record back sector by sector.
+//   LDS per wave: 4 records x SECT sectors x 1 KB (+ a 64-B skew per record index against bank conflicts).
+// Ordering: the DMA writes are covered by the wave's vmcnt (s_waitcnt vmcnt(0) before the read-back); the read-back is
+// drained (lgkmcnt(0)) before the next DMA may overwrite the regions.
+typedef __attribute__((address_space(3))) void* msm_lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* msm_gbl_ptr_t;
+
 template <class G>
-__global__ void __launch_bounds__(256, G::ACC_WAVES) k_accumulate_coop(const uint2* __restrict__ entries, const uint32_t* __restrict__ n_real,
+__global__ void __launch_bounds__(256, G::ACC_WAVES) k_accumulate_glds(const uint2* __restrict__ entries, const uint32_t* __restrict__ n_real,
                                                          uint32_t K, const typename G::BaseDev* __restrict__ bases,
                                                          SegOutT<typename G::T> out, uint32_t nlanes, uint32_t* __restrict__ flags) {
   using E = typename G::E;
   using Base = typename G::Base;
   constexpr int SECT = sizeof(typename G::BaseDev) / 64;   // 64-B sectors per record
-  constexpr int LS = G::COOP_LDS_STRIDE;                   // bytes per record slot in LDS
-  constexpr int PIECES = (sizeof(Base) + 15) / 16;
-  static_assert(sizeof(typename G::BaseDev) % 64 == 0 && LS % 16 == 0 && LS >= SECT * 64 && LS >= PIECES * 16, "record slot layout");
-  __shared__ __attribute__((aligned(16))) unsigned char lds[256 * LS];
+  constexpr int RS = 1024;                                 // bytes of one (record index, sector) region: 64 lanes x 16 B
+  constexpr int WAVE_LDS = 4 * SECT * RS + 256;
+  static_assert(sizeof(typename G::BaseDev) % 64 == 0 && SECT >= 2 && SECT <= 4, "record layout");
+  __shared__ __attribute__((aligned(16))) unsigned char lds[4 * WAVE_LDS];
   const uint32_t t = blockIdx.x * 256 + threadIdx.x;
-  const uint32_t sub = threadIdx.x & 3;
+  const uint32_t lane = threadIdx.x & 63, sub = lane & 3, quad = lane >> 2;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  unsigned char* wave_lds = lds + wave * WAVE_LDS;
+  // my record: index `sub` within my quad; its sector c starts at rec + c * RS
+  const unsigned char* rec = wave_lds + sub * (SECT * RS + 64) + quad * 64;
   typename E::Md md;
   const bool lane_ok = t < nlanes;
   if (lane_ok) {
     out.slot_keys[2 * (size_t)t] = KEY_NONE;
     out.slot_keys[2 * (size_t)t + 1] = KEY_NONE;
   }
-  const uint32_t n_entries = *n_real;   // zero digits produce no entry: the count of real ones lives on the device
+  const uint32_t n_entries = *n_real;
   const uint64_t beg64 = (uint64_t)t * K;
   const bool has_work = lane_ok && beg64 < n_entries;
   const uint32_t beg = has_work ? (uint32_t)beg64 : 0;
@@ -193,62 +206,40 @@ __global__ void __launch_bounds__(256, G::ACC_WAVES) k_accumulate_coop(const uin
   }
   bool alive = end > beg;
 
-  // The quad's four gathers: record i belongs to quad lane i; a lane without a next entry asks for record 0.
-  // (Twelve named registers and macros rather than an array and lambdas: hipcc leaves a loop-carried array in scratch.)
-  static_assert(SECT == 2 || SECT == 3, "the piece registers below are written out for two- and three-sector records");
-  uint4 q00, q01, q02, q10, q11, q12, q20, q21, q22, q30, q31, q32;
-#define MSM_COOP_ISSUE(val, valid)                                                                                      \
-  do {                                                                                                                  \
-    const int mine_ = (valid) ? (int)((val) & IDX_MASK) : 0;                                                            \
-    const uint4* s0_ = reinterpret_cast<const uint4*>(bases + (uint32_t)__builtin_amdgcn_update_dpp(0, mine_, 0x00, 0xf, 0xf, true)) + sub; \
-    const uint4* s1_ = reinterpret_cast<const uint4*>(bases + (uint32_t)__builtin_amdgcn_update_dpp(0, mine_, 0x55, 0xf, 0xf, true)) + sub; \
-    const uint4* s2_ = reinterpret_cast<const uint4*>(bases + (uint32_t)__builtin_amdgcn_update_dpp(0, mine_, 0xaa, 0xf, 0xf, true)) + sub; \
-    const uint4* s3_ = reinterpret_cast<const uint4*>(bases + (uint32_t)__builtin_amdgcn_update_dpp(0, mine_, 0xff, 0xf, 0xf, true)) + sub; \
-    q00 = s0_[0]; q01 = s0_[4];                                                                                         \
-    q10 = s1_[0]; q11 = s1_[4];                                                                                         \
-    q20 = s2_[0]; q21 = s2_[4];                                                                                         \
-    q30 = s3_[0]; q31 = s3_[4];                                                                                         \
-    if (SECT == 3) {                                                                                                    \
-      q02 = s0_[8]; q12 = s1_[8]; q22 = s2_[8]; q32 = s3_[8];                                                           \
-    }                                                                                                                   \
+#define MSM_GLDS_ONE(i, ctrl)                                                                                            \
+  do {                                                                                                                   \
+    const uint4* s_ = reinterpret_cast<const uint4*>(bases + (uint32_t)__builtin_amdgcn_update_dpp(0, mine_, ctrl, 0xf, 0xf, true)) + sub; \
+    _Pragma("unroll") for (int c_ = 0; c_ < SECT; c_++)                                                                  \
+      __builtin_amdgcn_global_load_lds((msm_gbl_ptr_t)(s_ + 4 * c_), (msm_lds_ptr_t)(wave_lds + (i) * (SECT * RS + 64) + c_ * RS), 16, 0, 0); \
   } while (0)
-#define MSM_COOP_PUT(i, c, reg) *reinterpret_cast<uint4*>(quad_slots + (i) * LS + (c) * 64 + sub * 16) = reg
+#define MSM_GLDS_ISSUE(val, valid)                                \
+  do {                                                            \
+    const int mine_ = (valid) ? (int)((val) & IDX_MASK) : 0;      \
+    MSM_GLDS_ONE(0, 0x00);                                        \
+    MSM_GLDS_ONE(1, 0x55);                                        \
+    MSM_GLDS_ONE(2, 0xaa);                                        \
+    MSM_GLDS_ONE(3, 0xff);                                        \
+  } while (0)
 
-  MSM_COOP_ISSUE(val_c, alive);
+  MSM_GLDS_ISSUE(val_c, alive);
   uint32_t cur = KEY_NONE;
   bool first = true, fresh = true, bad = false;
   XyzzT<typename G::T> acc;
   G::set_identity(acc);
   for (uint32_t k = 0; k < K; k++) {
     if (__builtin_amdgcn_ballot_w64(alive) == 0) break;   // wave-uniform: every lane of the wave has run out
-    // hand the pieces over through LDS and read this lane's record back as one contiguous run
     Base p;
-    {
-      unsigned char* quad_slots = lds + (threadIdx.x & ~3u) * LS;
-      MSM_COOP_PUT(0, 0, q00); MSM_COOP_PUT(0, 1, q01);
-      MSM_COOP_PUT(1, 0, q10); MSM_COOP_PUT(1, 1, q11);
-      MSM_COOP_PUT(2, 0, q20); MSM_COOP_PUT(2, 1, q21);
-      MSM_COOP_PUT(3, 0, q30); MSM_COOP_PUT(3, 1, q31);
-      if (SECT == 3) {
-        MSM_COOP_PUT(0, 2, q02); MSM_COOP_PUT(1, 2, q12); MSM_COOP_PUT(2, 2, q22); MSM_COOP_PUT(3, 2, q32);
-      }
-      // The pieces cross lanes of ONE wave: LDS operations of a wave execute in order, so no s_barrier is needed -- but the
-      // compiler must not move the read-back above the stores, nor the next iteration's stores above this read-back.
-      // Wavefront-scope fences + wave_barrier are zero-instruction scheduling barriers that say exactly that.
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      G::load_record(p, lds + threadIdx.x * LS, alive && (val_c >> 31) != 0);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the DMA of this entry's records has landed
+    __builtin_amdgcn_wave_barrier();
+    G::load_sectors(p, rec, RS, alive && (val_c >> 31) != 0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // ... and has been read, before the next DMA overwrites it
+    __builtin_amdgcn_wave_barrier();
     const uint32_t key = key_c, val = val_c, e = beg + k;
     const bool add_now = alive;
     key_c = key_n;
     val_c = val_n;
     alive = add_now && (end - e > 1);
-    MSM_COOP_ISSUE(val_c, alive);
+    MSM_GLDS_ISSUE(val_c, alive);
     if (add_now && end - e > 2) {
       const uint2 e2 = entries[e + 2];
       key_n = e2.y;
@@ -271,8 +262,8 @@ __global__ void __launch_bounds__(256, G::ACC_WAVES) k_accumulate_coop(const uin
   }
   if (cur != KEY_NONE) seg_flush(out, t, nlanes, cur, acc, first, true);
   if (G::CHECKS && bad) flags[1] = 1;
-#undef MSM_COOP_ISSUE
-#undef MSM_COOP_PUT
+#undef MSM_GLDS_ISSUE
+#undef MSM_GLDS_ONE
 }
 
 // Merge run fragments: same walk over the slot sequence of the previous level (keys non-decreasing,
@@ -470,10 +461,10 @@ __global__ void __launch_bounds__(256) k_te_convert(const AffineDev* __restrict_
   Fe inv;
   fe_inv<F>(inv, run, md);
   for (uint64_t j = hi; j-- > lo;) {
-    TeAffineDev o;
-    fe_set(o.p.ymx, F::ONE);   // the identity (0, 1): a harmless filler
-    fe_set(o.p.ypx, F::ONE);
-    fe_zero(o.p.td);
+    TeAffine o;
+    fe_set(o.ymx, F::ONE);   // the identity (0, 1): a harmless filler
+    fe_set(o.ypx, F::ONE);
+    fe_zero(o.td);
     if (!inf[j]) {
       const AffineDev a = in[j];
       Fe u, v, w, den;
@@ -483,10 +474,12 @@ __global__ void __launch_bounds__(256) k_te_convert(const AffineDev* __restrict_
         const Fe pre = prefix[j];
         fe_mul<F>(ti, inv, pre, md);      // 1 / den_j
         fe_mul<F>(inv, inv, den, md);
-        te_map_finish<F>(o.p, u, v, w, ti, md);
+        te_map_finish<F>(o, u, v, w, ti, md);
       }
     }
-    out[j] = o;
+    TeAffineDev od;
+    od.set(o);
+    out[j] = od;
   }
   if (bad) atomicAdd(&flags[0], bad);
 }

@@ -102,6 +102,31 @@ __device__ __forceinline__ uint32_t l1_tile(uint32_t block, uint32_t ntiles) {
   return (block & 7) * per_xcd + (block >> 3);
 }
 
+// Rank of an entry among the entries of its bin, and the bin's population, when there are only a FEW bins (b1 <= 8: small
+// inputs, whose level 1 resolves few bits).  A plain LDS atomic per entry then serialises on a handful of addresses
+// (8192 entries of a tile on ONE counter: 4 us per window, 0.5 ms for a 2^14 MSM); here the lanes of a wave that share a bin
+// are counted with a ballot and ONE lane adds their number to the counter.
+__device__ __forceinline__ uint32_t few_bins_rank(uint32_t* cnt, uint32_t b1, bool ok, uint32_t bin) {
+  uint64_t mine = 0;
+  for (uint32_t v = 0; v < b1; v++) {
+    const uint64_t m = __builtin_amdgcn_ballot_w64(ok && bin == v);
+    if (bin == v) mine = m;
+  }
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t before = (uint32_t)__popcll(mine & ((1ull << lane) - 1));
+  const int leader = mine ? __ffsll((unsigned long long)mine) - 1 : 0;
+  uint32_t base = 0;
+  if (ok && (int)lane == leader) base = atomicAdd(&cnt[bin], (uint32_t)__popcll(mine));
+  base = __shfl(base, leader, 64);
+  return base + before;
+}
+__device__ __forceinline__ void few_bins_count(uint32_t* cnt, uint32_t b1, uint32_t bin_base, bool ok, uint32_t bin) {
+  for (uint32_t v = 0; v < b1; v++) {
+    const uint64_t m = __builtin_amdgcn_ballot_w64(ok && bin == v);
+    if (m && (threadIdx.x & 63) == (uint32_t)(__ffsll((unsigned long long)m) - 1)) atomicAdd(&cnt[bin_base + v], (uint32_t)__popcll(m));
+  }
+}
+
 // Level-1 bin of (window w, bucket b): window-major normally; bucket-major with shared buckets, so that the W runs of one
 // bucket range are neighbours and form ONE segment for the next pass.
 __device__ __forceinline__ uint32_t l1_bin(const PartPlan& p, uint32_t w, uint32_t bucket) {
@@ -115,31 +140,59 @@ template <class FR, bool MONT>
 __global__ void __launch_bounds__(PART_THREADS) k_l1_hist(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ inf, PartPlan p,
                                                           uint32_t* __restrict__ matrix) {
   extern __shared__ uint32_t hist[];   // nbins
-  const uint32_t tile = l1_tile(blockIdx.x, p.ntiles);
+  const uint32_t tile = l1_tile(blockIdx.x / p.wgroups, p.ntiles);
   if (tile >= p.ntiles) return;
+  const uint32_t w_lo = (blockIdx.x % p.wgroups) * p.wper, w_hi = min(p.windows, w_lo + p.wper);   // this block's windows
   for (uint32_t b = threadIdx.x; b < p.nbins; b += PART_THREADS) hist[b] = 0;
   __syncthreads();
   const uint32_t wmask = (1u << p.c) - 1;
   const uint32_t i0 = tile * PART_TILE;
+  const bool few = p.b1 <= 8;   // wave-uniform
 #pragma unroll 1
   for (int k = 0; k < PART_PER_THREAD; k++) {
     const uint32_t i = i0 + threadIdx.x + k * PART_THREADS;
-    if (i >= p.n) break;
+    const bool have = i < p.n;
+    if (!few && !have) break;
     ScalarDigits st;
-    load_scalar<FR, MONT>(st, scalars, i);
-    const bool dead0 = p.table_stride ? false : inf[p.idx0 + i] != 0;
+    if (have) {
+      load_scalar<FR, MONT>(st, scalars, i);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; j++) st.s[j] = 0;
+      st.carry = 0;
+    }
+    const bool dead0 = !have || (p.table_stride ? false : inf[p.idx0 + i] != 0);
     for (uint32_t w = 0; w < p.windows; w++) {
       uint32_t mag;
       bool neg;
       next_digit(st, p.c, p.half, wmask, mag, neg);
+      if (w < w_lo || w >= w_hi) continue;   // (block-uniform) another block of this tile counts that window
       bool dead = dead0;
-      if (p.table_stride) dead = inf[p.idx0 + i + w * p.table_stride] != 0;
-      if (mag != 0 && !dead) atomicAdd(&hist[l1_bin(p, w, mag - 1)], 1u);
+      if (have && p.table_stride) dead = inf[p.idx0 + i + w * p.table_stride] != 0;
+      const bool ok = mag != 0 && !dead;
+      if (few) {
+        // every lane of the wave takes part in the ballots (lanes past the end contribute nothing)
+        const uint32_t hi = ok ? (mag - 1) >> p.lb : 0;
+        if (p.shared) {
+          for (uint32_t v = 0; v < p.b1; v++) {
+            const uint64_t m = __builtin_amdgcn_ballot_w64(ok && hi == v);
+            if (m && (threadIdx.x & 63) == (uint32_t)(__ffsll((unsigned long long)m) - 1)) atomicAdd(&hist[v * p.windows + w], (uint32_t)__popcll(m));
+          }
+        } else {
+          few_bins_count(hist, p.b1, w * p.b1, ok, hi);
+        }
+      } else if (ok) {
+        atomicAdd(&hist[l1_bin(p, w, mag - 1)], 1u);
+      }
     }
   }
   __syncthreads();
+  // the row of a tile is written by its blocks together: each the bins of its own windows
   uint32_t* row = matrix + (size_t)tile * p.nbins;
-  for (uint32_t b = threadIdx.x; b < p.nbins; b += PART_THREADS) row[b] = hist[b];
+  for (uint32_t b = threadIdx.x; b < p.nbins; b += PART_THREADS) {
+    const uint32_t w = p.shared ? b % p.windows : b / p.b1;
+    if (w >= w_lo && w < w_hi) row[b] = hist[b];
+  }
 }
 
 // Column scan of the [ntiles x nbins] matrix, three small kernels:
@@ -260,9 +313,11 @@ __global__ void __launch_bounds__(PART_THREADS) k_l1_scatter(const uint32_t* __r
   __shared__ uint2 stage[PART_TILE];
   __shared__ uint32_t offs[1 << PART_MAX_HB], cnt[1 << PART_MAX_HB], tstart[(1 << PART_MAX_HB) + 1];
   __shared__ uint32_t tmp[32];
-  const uint32_t tile = l1_tile(blockIdx.x, p.ntiles);
+  const uint32_t tile = l1_tile(blockIdx.x / p.wgroups, p.ntiles);
   if (tile >= p.ntiles) return;
+  const uint32_t w_lo = (blockIdx.x % p.wgroups) * p.wper, w_hi = min(p.windows, w_lo + p.wper);   // this block's windows
   const uint32_t wmask = (1u << p.c) - 1, lowmask = (1u << p.lb) - 1;
+  const bool few = p.b1 <= 8;   // wave-uniform
   const uint32_t i0 = tile * PART_TILE;
   ScalarDigits st[PART_PER_THREAD];
   uint32_t alive = 0;     // bit k: scalar k exists and (without tables) its base is not flagged infinite
@@ -281,12 +336,21 @@ __global__ void __launch_bounds__(PART_THREADS) k_l1_scatter(const uint32_t* __r
   const uint32_t* row = matrix + (size_t)tile * p.nbins;
   // the run offsets of the next window are fetched a whole window step ahead (a global load in the step's critical path
   // would cost ~1.5 us of the ~10 us a step takes)
-  uint32_t offs_next = threadIdx.x < p.b1 ? row[p.shared ? threadIdx.x * p.windows : threadIdx.x] : 0;
-  for (uint32_t w = 0; w < p.windows; w++) {
+  // windows below this block's range only advance the digit state (their carry feeds ours)
+  for (uint32_t w = 0; w < w_lo; w++) {
+#pragma unroll
+    for (int k = 0; k < PART_PER_THREAD; k++) {
+      uint32_t mag;
+      bool neg;
+      next_digit(st[k], p.c, p.half, wmask, mag, neg);
+    }
+  }
+  uint32_t offs_next = threadIdx.x < p.b1 ? row[p.shared ? threadIdx.x * p.windows + w_lo : w_lo * p.b1 + threadIdx.x] : 0;
+  for (uint32_t w = w_lo; w < w_hi; w++) {
     if (threadIdx.x < p.b1) {
       cnt[threadIdx.x] = 0;
       offs[threadIdx.x] = offs_next;
-      if (w + 1 < p.windows) offs_next = row[p.shared ? threadIdx.x * p.windows + (w + 1) : (w + 1) * p.b1 + threadIdx.x];
+      if (w + 1 < w_hi) offs_next = row[p.shared ? threadIdx.x * p.windows + (w + 1) : (w + 1) * p.b1 + threadIdx.x];
     }
     __syncthreads();
     uint32_t where[PART_PER_THREAD];   // bin << 16 | rank in the tile's bin; 0xffffffff = no entry
@@ -301,9 +365,13 @@ __global__ void __launch_bounds__(PART_THREADS) k_l1_scatter(const uint32_t* __r
       const uint32_t idx = p.idx0 + i + w * p.table_stride;
       if (ok && p.table_stride) ok = inf[idx] == 0;
       where[k] = 0xffffffffu;
+      const uint32_t bucket = ok ? mag - 1 : 0, hi = bucket >> p.lb;
+      uint32_t rank = 0;
+      if (few)
+        rank = few_bins_rank(cnt, p.b1, ok, hi);      // all lanes: ballots inside
+      else if (ok)
+        rank = atomicAdd(&cnt[hi], 1u);
       if (ok) {
-        const uint32_t bucket = mag - 1, hi = bucket >> p.lb;
-        const uint32_t rank = atomicAdd(&cnt[hi], 1u);
         where[k] = (hi << 16) | rank;
         ent[k] = make_uint2(idx | (neg ? 0x80000000u : 0u), (bucket & lowmask) | (hi << 16));   // lb <= 15
       }
@@ -507,7 +575,7 @@ inline int part_run(const uint32_t* d_scalars, const uint8_t* d_inf, const PartP
   err = hipSuccess;
   const uint64_t entries = (uint64_t)p.n * p.windows;
   const dim3 scan_grid(part_ceil_div(p.nbins, 256), PART_SCAN_GROUPS);
-  const uint32_t l1_grid = 8 * ((p.ntiles + 7) / 8);   // l1_tile(): a contiguous tile range per XCD
+  const uint32_t l1_grid = 8 * ((p.ntiles + 7) / 8) * p.wgroups;   // l1_tile(): a contiguous tile range per XCD; wgroups blocks per tile
   hipLaunchKernelGGL((k_l1_hist<FR, MONT>), dim3(l1_grid), dim3(PART_THREADS), p.nbins * 4, st, d_scalars, d_inf, p, b.matrix);
   hipLaunchKernelGGL(k_l1_scan_a, scan_grid, dim3(256), 0, st, b.matrix, p, b.partial);
   hipLaunchKernelGGL(k_l1_scan_b, dim3(1), dim3(1024), 0, st, b.partial, p, b.segs[0], b.subjob_first, b.totals);

@@ -42,6 +42,7 @@ struct PartPlan {
   uint32_t nbins;                    // level-1 bins = segments after level 1: windows * b1
   uint32_t ntiles;                   // ceil(n / PART_TILE)
   uint32_t tiles_per_group;          // column-scan grouping
+  uint32_t wgroups, wper;            // level-1 blocks per tile (each takes `wper` consecutive windows): fills the chip when tiles are few
 };
 
 // Geometry of one generic pass.
@@ -79,6 +80,12 @@ inline PartPlan part_plan(uint32_t n, uint32_t c, uint32_t windows, bool shared,
   p.ntiles = part_ceil_div(n, PART_TILE);
   if (p.ntiles == 0) p.ntiles = 1;
   p.tiles_per_group = part_ceil_div(p.ntiles, PART_SCAN_GROUPS);
+  // A level-1 block walks its windows one after the other (~5 us each): with few tiles, give every tile several blocks that
+  // split the windows between them (the scalars are read once more per block; at these sizes that is nothing)
+  const uint32_t want = p.ntiles >= 256 ? 1 : part_ceil_div(256, p.ntiles);
+  p.wgroups = std::min<uint32_t>(windows, want);
+  p.wper = part_ceil_div(windows, p.wgroups);
+  p.wgroups = part_ceil_div(windows, p.wper);
   return p;
 }
 

@@ -27,9 +27,29 @@ namespace msm {
 struct TeAffine {
   Fe ymx, ypx, td;   // Y - X, Y + X, 2 d X Y
 };
-// 168 B padded to three 64-B sectors, so one lane's gather touches exactly three
+// Device record: ONE FIELD PER 64-B SECTOR (56 B + 8 B of padding), 192 B.  A gather touches exactly three sectors, and a
+// kernel that receives the record sector by sector (k_accumulate_glds) applies the negation swap by choosing which sector it
+// reads Y - X from.
 struct alignas(64) TeAffineDev {
-  TeAffine p;
+  Fe ymx;
+  uint32_t pad0[2];
+  Fe ypx;
+  uint32_t pad1[2];
+  Fe td;
+  uint32_t pad2[2];
+  MSM_HD TeAffine get() const {
+    TeAffine t;
+    t.ymx = ymx;
+    t.ypx = ypx;
+    t.td = td;
+    return t;
+  }
+  MSM_HD void set(const TeAffine& t) {
+    ymx = t.ymx;
+    ypx = t.ypx;
+    td = t.td;
+    pad0[0] = pad0[1] = pad1[0] = pad1[1] = pad2[0] = pad2[1] = 0;
+  }
 };
 static_assert(sizeof(TeAffineDev) == 192, "device twisted-Edwards base layout");
 

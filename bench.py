@@ -310,6 +310,29 @@ def main():
                 out["survey_8d_metrics"] = extras
             except Exception as e:   # never lose the headline line to a secondary measurement
                 out["survey_8d_metrics"] = {"error": repr(e)}
+        if world == 1 and not c_sharded and args.extras and cid == 0 and args.npow == 26:
+            # BASELINE.json configs[2] and configs[4], measured in the same run so that the driver's line carries them:
+            # the second 384-bit prime (no Edwards form: XYZZ) and G2 over Fq2.  Scalars resident in HBM, as for `value`.
+            ctx.close()   # hand the headline context's memory back first
+            sec = {}
+            for name, cname, npow2 in (("bls12_381_g1_2^26", "bls12_381_g1", 26), ("bls12_377_g2_2^24", "bls12_377_g2", 24)):
+                try:
+                    cid2, n2 = ea.CURVE_IDS[cname], 1 << npow2
+                    tile2 = torch.from_numpy(ea.generate_points(distinct, distinct=distinct, seed=0x5A5052495A45 + cid2, curve=cname)).to(device)
+                    sc2 = uniform_scalars(n2, R381_TOP if cid2 == 1 else R377_TOP, device, seed=99 + cid2)
+                    c2 = ea.MultiScalarMultContext(cname, device=local_rank)
+                    c2.set_bases(tile2.repeat(n2 // distinct, 1).contiguous())
+                    ms2, _ = timed(lambda: c2.run(sc2)[0], 3)
+                    tm2 = c2.last_timings()
+                    k_ms = tm2["accumulate"] / max(tm2["launches"], 1)
+                    sec[name] = {"ms_per_step": ms2, "value": n2 / ms2 * 1e3, "unit": "pairs/s", "window_bits": tm2["window_bits"],
+                                 "stage_ms": {k: tm2[k] for k in ("digits", "sort", "accumulate", "segreduce", "bucket_reduce", "host_fold")},
+                                 "roofline_frac_hbm": BYTES_PER_PAIR[cid2] * n2 / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+                    c2.close()
+                    del tile2, sc2
+                except Exception as e:
+                    sec[name] = {"error": repr(e)}
+            out["secondary_configs"] = sec
         if world == 1 and not c_sharded and args.cpu_sample_pow > 0:
             sample = min(n, 1 << args.cpu_sample_pow)
             cores = os.cpu_count() or 1
@@ -321,8 +344,15 @@ def main():
             windows = -(-(255 if cid == 1 else 253) // c)
             threads = min(windows, cores)
             v, cpu_res, dt = cpu_baseline(args.curve, cid, bases_np, scal_np, sample, threads)
-            # same sample on the GPU: a parity spot-check next to the number
-            gpu_res = ctx.run(scalars[:sample].contiguous(), npoints=sample)[0]
+            # same sample on the GPU: a parity spot-check next to the number (`result` is the headline run's point when the
+            # sample is the whole workload; otherwise a context over the sample's bases recomputes it)
+            if sample == n:
+                gpu_res = result
+            else:
+                cs = ea.MultiScalarMultContext(args.curve, device=local_rank)
+                cs.set_bases(torch.from_numpy(bases_np).to(device))
+                gpu_res = cs.run(scalars[:sample].contiguous())[0]
+                cs.close()
             out["cpu_baseline"] = {"value": v, "unit": "pairs/s", "cores": threads, "kind": "port",
                                    "sample": f"first 2^{sample.bit_length() - 1} pairs of the same workload, {dt:.1f} s, "
                                              f"arkworks-algorithm restatement (c={c}, one thread per window), host has {cores} cores",

@@ -25,10 +25,10 @@ def _compile_kernel(instantiation):
         assert r.returncode == 0, r.stderr[-2000:]
         asm = open(os.path.join(d, "acc-hip-amdgcn-amd-amdhsa-gfx950.s")).read()
         remarks = r.stderr
-    body = asm[asm.index("_ZN3msm17k_accumulate_coop"):]
+    body = asm[asm.index("_ZN3msm17k_accumulate_glds"):]
     body = body[:body.index("s_endpgm")]
     ops = re.findall(r"^\s+([a-z_0-9]+)", body, flags=re.M)
-    blk = remarks[remarks.index("k_accumulate_coop"):]
+    blk = remarks[remarks.index("k_accumulate_glds"):]
     res = {k: int(re.search(pat, blk).group(1)) for k, pat in
            (("scratch", r"ScratchSize \[bytes/lane\]: (\d+)"), ("occupancy", r"Occupancy \[waves/SIMD\]: (\d+)"),
             ("vgprs", r"VGPRs: (\d+)"), ("lds", r"LDS Size \[bytes/block\]: (\d+)"))}
@@ -39,10 +39,10 @@ def _compile_kernel(instantiation):
 @pytest.mark.parametrize("law", ["sw", "te"])
 def test_accumulate_kernel_isa(law):
     if law == "sw":
-        inst = ("template __global__ void k_accumulate_coop<SwLaw<FpEl<Bls12_377_Fq>>>(const uint2*, const uint32_t*, uint32_t, "
+        inst = ("template __global__ void k_accumulate_glds<SwLaw<FpEl<Bls12_377_Fq>>>(const uint2*, const uint32_t*, uint32_t, "
                 "const AffineDev*, SegOut, uint32_t, uint32_t*);")
     else:
-        inst = ("template __global__ void k_accumulate_coop<TeLaw<Bls12_377_Fq>>(const uint2*, const uint32_t*, uint32_t, "
+        inst = ("template __global__ void k_accumulate_glds<TeLaw<Bls12_377_Fq>>(const uint2*, const uint32_t*, uint32_t, "
                 "const TeAffineDev*, SegOut, uint32_t, uint32_t*);")
     body, ops, res = _compile_kernel(inst)
     assert "s_set_gpr_idx_on" not in body and "v_accvgpr" not in body
@@ -57,14 +57,13 @@ def test_accumulate_kernel_isa(law):
         assert 2646 <= mads <= 2700, mads
     assert carries < 50, carries            # the multiply-add chain is carry-free by construction
     assert res["scratch"] <= 32 and res["occupancy"] >= 2 and res["vgprs"] <= 256
-    assert 256 * 128 <= res["lds"] <= 80 * 1024     # the record slots of the quad-cooperative gather; two blocks per CU fit in 160 KB
-    # the gathers are 16-B per lane and the pieces cross lanes through LDS
-    assert ops.count("ds_write_b128") >= 8
-    if law == "sw":
-        assert ops.count("ds_read_b128") >= 7
-    else:
-        # Y - X and Y + X are read from each other's place for a negated base: 8-byte reads at a per-lane address
-        assert 2 * ops.count("ds_read2_b64") + ops.count("ds_read_b64") >= 14 and ops.count("v_cndmask_b32_e64") <= 24
+    assert 32 * 1024 <= res["lds"] <= 53 * 1024     # 4 waves x 4 records x SECT sectors x 1 KB (+ skew): three blocks per CU fit in 160 KB
+    # the gathers are LDS-DMA (global -> LDS, no VGPR staging, no ds_write): 4 records x SECT sectors per addition
+    sect = 2 if law == "sw" else 3
+    assert ops.count("global_load_lds_dwordx4") == 2 * 4 * sect and ops.count("ds_write_b128") == 0
+    if law == "te":
+        # Y - X and Y + X are read from each other's sector for a negated base: per-lane LDS addresses, 14 selects left (2dXY)
+        assert ops.count("v_cndmask_b32_e64") <= 24 and res["vgprs"] <= 168      # 3 waves/SIMD resident
     # selects must be the VOP3 form: v_cndmask_b32_e32 (mask implicit in VCC) issues at 22.9 cycles on gfx950 against 4.2 for
     # v_cndmask_b32_e64 (profiles/r02_ubench_valu_w4.txt); the sign handling of a mixed addition is 28-42 of them
     assert ops.count("v_cndmask_b32_e32") <= 2, ops.count("v_cndmask_b32_e32")
