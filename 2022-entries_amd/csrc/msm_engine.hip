@@ -158,7 +158,7 @@ struct mi355_msm_ctx {
   hipEvent_t ev[8] = {};
   long opt_window_bits = 0, opt_lane_entries = 0, opt_max_chunk = 0, opt_seg_entries = 0, opt_scalars_montgomery = 0;
   long opt_precompute = 0;
-  long opt_reduce_log_chunk = 0;
+  long opt_reduce_log_chunk = 0, opt_reduce_log_chunk0 = 0;
   long opt_twisted_edwards = 1;   // BLS12-377 G1 only: accumulate on the twisted-Edwards image when every base has one
   // twisted-Edwards fast path (te.hpp): records for every table level; te_active is decided per base set
   DevBuf te_bases, flags;         // flags: u32[2] on the device, [0] bases without an image, [1] an addition failed
@@ -212,6 +212,7 @@ struct mi355_msm_ctx {
     p.logL0 = std::min<uint32_t>(7, std::max<uint32_t>(2, l0));
     p.logL = 2;
     if (opt_reduce_log_chunk) p.logL0 = p.logL = (uint32_t)opt_reduce_log_chunk;
+    if (opt_reduce_log_chunk0) p.logL0 = (uint32_t)opt_reduce_log_chunk0;   // first level only
     p.logL0 = std::min<uint32_t>(p.logL0, p.c - 1 ? p.c - 1 : 1);
     p.T0 = ceil_div(p.half, 1u << p.logL0);
     return p;
@@ -997,6 +998,9 @@ RustError mi355_msm_set_option(mi355_msm_ctx* ctx, const char* key, long value) 
     } else if (k == "reduce_log_chunk") {
       if (value < 0 || value > 7) bad_arg("reduce_log_chunk %ld out of range [1, 7]", value);
       ctx->opt_reduce_log_chunk = value;
+    } else if (k == "reduce_log_chunk0") {
+      if (value < 0 || value > 7) bad_arg("reduce_log_chunk0 %ld out of range [1, 7]", value);
+      ctx->opt_reduce_log_chunk0 = value;
     } else if (k == "twisted_edwards") {
       ctx->opt_twisted_edwards = value != 0;   // takes effect at the next set_bases
     } else if (k == "precompute") {

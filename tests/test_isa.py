@@ -64,8 +64,9 @@ def test_accumulate_kernel_isa(law):
     if law == "te":
         # Y - X and Y + X are read from each other's sector for a negated base: per-lane LDS addresses, 14 selects left (2dXY)
         assert ops.count("v_cndmask_b32_e64") <= 24 and res["vgprs"] <= 168      # 3 waves/SIMD resident
-    # selects must be the VOP3 form: v_cndmask_b32_e32 (mask implicit in VCC) issues at 22.9 cycles on gfx950 against 4.2 for
-    # v_cndmask_b32_e64 (profiles/r02_ubench_valu_w4.txt); the sign handling of a mixed addition is 28-42 of them
+    # selects are emitted in the VOP3 form: back-to-back v_cndmask_b32_e32 (mask implicit in VCC) issue at 22.9 cycles in isolation
+    # against 4.2 for v_cndmask_b32_e64 (profiles/r02_ubench_valu_w4.txt).  In this kernel the difference did not show
+    # (profiles/r02_ab_cndmask.txt); the form is pinned anyway so that a scheduling change cannot bring the slow case back
     assert ops.count("v_cndmask_b32_e32") <= 2, ops.count("v_cndmask_b32_e32")
 
 

@@ -118,8 +118,8 @@ def test_against_reference_hostcurve_377(oracle):
         oracle.oracle_fp_mul(0, a.to_bytes(48, "little"), b.to_bytes(48, "little"), o1)
         ref.ref377_fp_mul(a.to_bytes(48, "little"), b.to_bytes(48, "little"), o2)
         assert o1.raw == o2.raw == ((a * b * pow(m.R, -1, c.p)) % c.p).to_bytes(48, "little")
-    for n in (1, 13, 40):
-        pts = m.random_points(c, n, rng, max(1, n // 3))
+    for n in (1, 13, 40, 700):
+        pts = m.random_points(c, n, rng, max(1, min(n // 3, 64)))
         sc = m.random_scalars(c, n, rng)
         if n > 3:
             pts[2] = None
@@ -133,10 +133,13 @@ def test_against_reference_hostcurve_377(oracle):
 def test_against_reference_c_msm_381(oracle):
     """A full MSM through the reference's C implementation (open-division/prize4-msm-wasm/yrrid/C/MSM.c)."""
     c = m.BLS12_381_G1
-    rng = random.Random(381)
-    n = 48
-    pts = m.random_points(c, n, rng, 12)
-    sc = m.random_scalars(c, n, rng)
+    for n, distinct in ((48, 12), (4096, 128)):
+        _check_ref381(oracle, c, n, distinct)
+
+
+def _run_ref381(c, pts, sc):
+    """(x, y) of sum k_i P_i as computed by the reference's C MSM binary (both of its algorithms must agree)."""
+    n = len(pts)
     with tempfile.TemporaryDirectory() as d:
         os.mkdir(os.path.join(d, "data"))
         with open(os.path.join(d, "data", "points.hex"), "w") as f:
@@ -150,6 +153,14 @@ def test_against_reference_c_msm_381(oracle):
     ys = [ln.split("=")[1].strip() for ln in r.stdout.splitlines() if ln.strip().startswith("y=")]
     ref_pt = (int(xs[0], 16), int(ys[0], 16))
     assert (int(xs[1], 16), int(ys[1], 16)) == ref_pt     # its simple and lambda MSMs agree
+    return ref_pt
+
+
+def _check_ref381(oracle, c, n, distinct):
+    rng = random.Random(381 + n)
+    pts = m.random_points(c, n, rng, distinct)
+    sc = m.random_scalars(c, n, rng)
+    ref_pt = _run_ref381(c, pts, sc)
     got = oracle_msm(oracle, 1, c.encode_affine_array(pts), m.encode_scalars(sc), n)
     assert got == c.encode_projective_normalized(ref_pt)
 

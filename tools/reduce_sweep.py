@@ -13,8 +13,8 @@ ctx = ea.MultiScalarMultContext(curve)
 ctx.set_bases(tile.repeat(n // distinct, 1).contiguous())
 sc = uniform_scalars(n, R377_TOP, torch.device("cuda"), 5)
 ref = None
-for rl in (0, 3, 4, 5, 6, 7):
-    ctx.set_option("reduce_log_chunk", rl)
+for rl in (0, 4, 5, 6, 7):
+    ctx.set_option("reduce_log_chunk0", rl)
     ctx.run(sc)
     t0 = time.perf_counter()
     for _ in range(3):
@@ -22,4 +22,4 @@ for rl in (0, 3, 4, 5, 6, 7):
     dt = (time.perf_counter() - t0) / 3 * 1e3
     tm = ctx.last_timings()
     ref = ref or r
-    print("reduce_log_chunk=%d  step %.2f ms  bucket_reduce %.3f  segreduce %.3f  accumulate %.2f  same=%s" % (rl, dt, tm["bucket_reduce"], tm["segreduce"], tm["accumulate"], r == ref))
+    print("reduce_log_chunk0=%d (later levels: chunks of 4)  step %.2f ms  bucket_reduce %.3f  segreduce %.3f  accumulate %.2f  same=%s" % (rl, dt, tm["bucket_reduce"], tm["segreduce"], tm["accumulate"], r == ref))
