@@ -38,4 +38,11 @@ hipError_t LaunchTe::bucket_reduce(bool first, const XyzzDev* in_a, const XyzzDe
   return hipGetLastError();
 }
 
+hipError_t LaunchTe::reduce_scan_step(const XyzzDev* in, const XyzzDev* in2, XyzzDev* out, uint32_t nb, uint32_t windows, uint32_t d, uint32_t mode, uint32_t* flags,
+                                      hipStream_t st) {
+  const uint64_t threads = (uint64_t)windows * (mode == 1 ? d : nb);
+  hipLaunchKernelGGL((k_reduce_scan_step<G>), dim3(te_blocks(threads)), dim3(256), 0, st, in, in2, out, nb, windows, d, mode, flags);
+  return hipGetLastError();
+}
+
 }  // namespace msm

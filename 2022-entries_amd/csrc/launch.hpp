@@ -25,6 +25,9 @@ struct Launch {
                                   hipStream_t st);
   static hipError_t bucket_reduce(bool first, const XyzzDevT<El>* in_a, const XyzzDevT<El>* in_x, uint32_t n_per_win, uint32_t logL,
                                   uint32_t chunks, uint32_t windows, XyzzDevT<El>* out_a, XyzzDevT<El>* out_x, hipStream_t st);
+  // small windows: one step of the scan-based reduction (k_reduce_scan_step)
+  static hipError_t reduce_scan_step(const XyzzDevT<El>* in, const XyzzDevT<El>* in2, XyzzDevT<El>* out, uint32_t nb, uint32_t windows, uint32_t d, uint32_t mode,
+                                     hipStream_t st);
 };
 
 // The twisted-Edwards fast path of BLS12-377 G1 (kernels_377te.hip).  `flags`: [0] += bases without an image (convert),
@@ -38,6 +41,8 @@ struct LaunchTe {
                               uint32_t* flags, hipStream_t st);
   static hipError_t bucket_reduce(bool first, const XyzzDev* in_a, const XyzzDev* in_x, uint32_t n_per_win, uint32_t logL, uint32_t chunks,
                                   uint32_t windows, XyzzDev* out_a, XyzzDev* out_x, uint32_t* flags, hipStream_t st);
+  static hipError_t reduce_scan_step(const XyzzDev* in, const XyzzDev* in2, XyzzDev* out, uint32_t nb, uint32_t windows, uint32_t d, uint32_t mode, uint32_t* flags,
+                                     hipStream_t st);
 };
 
 // Bucket grouping (partition.hip): digits + MSD partition of the (key, value) entries.  scalar_field: 0 = BLS12-377 Fr, 1 = BLS12-381 Fr

@@ -54,6 +54,14 @@ hipError_t Launch<E>::bucket_reduce(bool first, const XyzzDevT<El>* in_a, const 
 }
 
 template <class E>
+hipError_t Launch<E>::reduce_scan_step(const XyzzDevT<El>* in, const XyzzDevT<El>* in2, XyzzDevT<El>* out, uint32_t nb, uint32_t windows, uint32_t d, uint32_t mode,
+                                       hipStream_t st) {
+  const uint64_t threads = (uint64_t)windows * (mode == 1 ? d : nb);
+  hipLaunchKernelGGL((k_reduce_scan_step<SwLaw<E>>), dim3(launch_blocks(threads)), dim3(256), 0, st, in, in2, out, nb, windows, d, mode, (uint32_t*)nullptr);
+  return hipGetLastError();
+}
+
+template <class E>
 hipError_t Launch<E>::pre_double(const AffineDevT<El>* in, const uint8_t* inf_in, uint32_t n, uint32_t c, XyzzDevT<El>* out, hipStream_t st) {
   hipLaunchKernelGGL((k_pre_double<E>), dim3(launch_blocks(n)), dim3(256), 0, st, in, inf_in, n, c, out);
   return hipGetLastError();

@@ -67,6 +67,7 @@ struct SwLaw {
     for (uint32_t i = 0; i < k; i++) xyzz_dbl<E>(acc, md);
   }
   static MSM_HD bool failed(const XyzzT<T>&) { return false; }
+  static MSM_HD bool is_empty(const XyzzT<T>&) { return false; }   // XYZZ: all-zero IS the identity
 };
 
 template <class F>
@@ -120,6 +121,7 @@ struct TeLaw {
     }
   }
   static MSM_HD bool failed(const Xyzz& a) { return te_failed<F>(a); }
+  static MSM_HD bool is_empty(const Xyzz& a) { return fe_is_zero_M<F>(a.zz); }   // Z = 0 never occurs in a valid point
 };
 
 }  // namespace msm

@@ -130,13 +130,15 @@ int choose_window_bits(size_t n, int scalar_bits, bool shared_buckets) {
 }
 
 struct Plan {
-  uint32_t c, windows, half, sentinel, keybits;
+  uint32_t c, windows, half, keybits;
   uint32_t bucket_windows;  // windows that own buckets: `windows`, or 1 with precomputed tables
   uint64_t entries;     // windows * n
   uint32_t K, nlanes;   // accumulate geometry
   uint32_t segK;        // fragment-merge fan-in
   uint32_t logL0, logL; // bucket-reduce chunk sizes
   uint32_t T0;          // chunks per window on the first reduce level
+  bool reduce_scan;     // finish the bucket reduction by a parallel scan (k_reduce_scan_step) ...
+  bool scan_direct;     // ... directly on the buckets (small windows), or after one chunked level
 };
 
 }  // namespace
@@ -159,6 +161,7 @@ struct mi355_msm_ctx {
   long opt_window_bits = 0, opt_lane_entries = 0, opt_max_chunk = 0, opt_seg_entries = 0, opt_scalars_montgomery = 0;
   long opt_precompute = 0;
   long opt_reduce_log_chunk = 0, opt_reduce_log_chunk0 = 0;
+  long opt_reduce_scan = -1;      // 0: recursive chunked running sums only; otherwise the scan tail (default)
   long opt_twisted_edwards = 1;   // BLS12-377 G1 only: accumulate on the twisted-Edwards image when every base has one
   // twisted-Edwards fast path (te.hpp): records for every table level; te_active is decided per base set
   DevBuf te_bases, flags;         // flags: u32[2] on the device, [0] bases without an image, [1] an addition failed
@@ -199,8 +202,7 @@ struct mi355_msm_ctx {
     p.windows = (257 + p.c - 1) / p.c;
     p.bucket_windows = tables ? 1 : p.windows;
     p.half = 1u << (p.c - 1);
-    p.sentinel = p.bucket_windows * p.half;
-    p.keybits = ilog2_floor(p.sentinel) + 1;
+    p.keybits = ilog2_floor(p.bucket_windows * p.half) + 1;   // bits of a bucket key (reported by mi355_msm_plan)
     p.entries = (uint64_t)p.windows * n;
     uint32_t K = opt_lane_entries ? (uint32_t)opt_lane_entries : (uint32_t)std::min<uint64_t>(256, std::max<uint64_t>(8, p.entries >> 20));
     p.K = (K + 3) & ~3u;
@@ -214,6 +216,16 @@ struct mi355_msm_ctx {
     if (opt_reduce_log_chunk) p.logL0 = p.logL = (uint32_t)opt_reduce_log_chunk;
     if (opt_reduce_log_chunk0) p.logL0 = (uint32_t)opt_reduce_log_chunk0;   // first level only
     p.logL0 = std::min<uint32_t>(p.logL0, p.c - 1 ? p.c - 1 : 1);
+    // The tail of the reduction is latency, not work: once a window is down to <= 4096 elements it is finished by a parallel
+    // scan (one addition per thread and step).  Small windows (<= 4096 buckets) scan their buckets directly; larger ones run
+    // ONE chunked level that leaves at most 4096 chunks.
+    p.reduce_scan = opt_reduce_scan != 0;
+    p.scan_direct = p.reduce_scan && p.half <= 4096;
+    if (p.reduce_scan && !p.scan_direct) {
+      const uint32_t need = ilog2_floor(p.half) - 12;
+      if (p.logL0 < need) p.logL0 = need;
+      if (p.logL0 > 9) p.reduce_scan = false;   // (windows beyond 2^21 buckets: keep the recursive scheme)
+    }
     p.T0 = ceil_div(p.half, 1u << p.logL0);
     return p;
   }
@@ -228,7 +240,7 @@ uint64_t work_bytes(const Plan& p, uint64_t el) {
   const PartPlan pp = part_plan((uint32_t)(p.entries / p.windows), p.c, p.windows, p.bucket_windows == 1 && p.windows > 1, 0, 0);
   const PartScratchSizes ps = part_scratch_sizes(pp);
   return p.entries * 16 + ps.matrix + ps.partial + ps.segs_a + ps.segs_b + ps.subjob_first + ps.counts + ps.totals +
-         (uint64_t)p.bucket_windows * p.half * 224 * el + 2 * (2ull * p.nlanes) * (224 * el + 4) + 4ull * p.bucket_windows * p.T0 * 224 * el;
+         (uint64_t)p.bucket_windows * p.half * 224 * el + 2 * (2ull * p.nlanes) * (224 * el + 4) + (p.scan_direct ? (uint64_t)p.bucket_windows * p.half : 4ull * p.bucket_windows * p.T0) * 224 * el;
 }
 
 DevBuf* const* work_buffers(mi355_msm_ctx* ctx, size_t& count) {
@@ -480,10 +492,11 @@ bool run_chunk_impl(mi355_msm_ctx* ctx, const uint32_t* d_scalars, size_t base0,
     ctx->slots[i].reserve(nslots0 * sizeof(XyzzDev));
     ctx->slot_keys[i].reserve(nslots0 * 4);
   }
-  const size_t red0 = (size_t)p.bucket_windows * p.T0;
+  const size_t red0 = p.scan_direct ? nbuckets : (size_t)p.bucket_windows * p.T0;   // direct scan: a second bucket-sized array to ping-pong with
   for (int i = 0; i < 2; i++) {
+    if (p.scan_direct && i == 1) break;
     ctx->red_a[i].reserve(red0 * sizeof(XyzzDev));
-    ctx->red_x[i].reserve(red0 * sizeof(XyzzDev));
+    if (!p.scan_direct) ctx->red_x[i].reserve(red0 * sizeof(XyzzDev));
   }
   if (ctx->pinned_bytes < p.windows * sizeof(XyzzDev)) {
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
@@ -543,28 +556,65 @@ bool run_chunk_impl(mi355_msm_ctx* ctx, const uint32_t* d_scalars, size_t base0,
   HIP_OK(hipEventRecord(ctx->ev[4], st));
 
   // buckets -> one point per window
-  uint32_t n_per_win = p.half, logL = p.logL0, chunks = p.T0;
-  int rb = 0;
-  if constexpr (TE)
-    HIP_OK(LaunchTe::bucket_reduce(true, nullptr, ctx->buckets.as<XyzzDev>(), n_per_win, logL, chunks, p.bucket_windows,
-                                   ctx->red_a[0].as<XyzzDev>(), ctx->red_x[0].as<XyzzDev>(), flags, st));
-  else
-    HIP_OK(Launch<E>::bucket_reduce(true, nullptr, ctx->buckets.as<XyzzDev>(), n_per_win, logL, chunks, p.bucket_windows,
-                                    ctx->red_a[0].as<XyzzDev>(), ctx->red_x[0].as<XyzzDev>(), st));
-  while (chunks > 1) {
-    n_per_win = chunks;
-    logL = p.logL;
-    chunks = ceil_div(n_per_win, 1u << logL);
+  if (p.reduce_scan) {
+    // parallel scan, one addition per thread and step.  Direct: on the buckets, ping-pong with a second bucket-sized array.
+    // Otherwise: one chunked level first (A_t, X_t per chunk), scan on the X_t, join with the A_t, tree.
+    uint32_t nb = p.half;
+    XyzzDev* bufs[2] = {ctx->buckets.as<XyzzDev>(), ctx->red_a[0].as<XyzzDev>()};
+    const XyzzDev* a_sums = nullptr;
+    if (!p.scan_direct) {
+      if constexpr (TE)
+        HIP_OK(LaunchTe::bucket_reduce(true, nullptr, ctx->buckets.as<XyzzDev>(), p.half, p.logL0, p.T0, p.bucket_windows,
+                                       ctx->red_a[0].as<XyzzDev>(), ctx->red_x[0].as<XyzzDev>(), flags, st));
+      else
+        HIP_OK(Launch<E>::bucket_reduce(true, nullptr, ctx->buckets.as<XyzzDev>(), p.half, p.logL0, p.T0, p.bucket_windows,
+                                        ctx->red_a[0].as<XyzzDev>(), ctx->red_x[0].as<XyzzDev>(), st));
+      nb = p.T0;
+      a_sums = ctx->red_a[0].as<XyzzDev>();
+      bufs[0] = ctx->red_x[0].as<XyzzDev>();
+      bufs[1] = ctx->red_x[1].as<XyzzDev>();
+    }
+    int cur = 0;
+    auto step = [&](uint32_t d, uint32_t mode) {
+      if constexpr (TE)
+        HIP_OK(LaunchTe::reduce_scan_step(bufs[cur], a_sums, bufs[cur ^ 1], nb, p.bucket_windows, d, mode, flags, st));
+      else
+        HIP_OK(Launch<E>::reduce_scan_step(bufs[cur], a_sums, bufs[cur ^ 1], nb, p.bucket_windows, d, mode, st));
+      cur ^= 1;
+    };
+    for (uint32_t d = 1; d < nb; d <<= 1) step(d, 0);
+    if (a_sums) step(0, 2);
+    if (nb & (nb - 1)) bad_arg("scan reduction needs a power-of-two element count per window (%u)", nb);
+    for (uint32_t h = nb >> 1; h >= 1; h >>= 1) step(h, 1);   // out_j = in_j + in_(j+h) for j < h
+    if (nb == 1 && !a_sums) step(1, 0);   // a single bucket per window: one pass that normalises an empty bucket to the identity
+    HIP_OK(hipEventRecord(ctx->ev[5], st));
+    // the window sums sit at the head of each window's row
+    HIP_OK(hipMemcpy2DAsync(ctx->pinned, sizeof(XyzzDev), bufs[cur], (size_t)nb * sizeof(XyzzDev), sizeof(XyzzDev), p.bucket_windows,
+                            hipMemcpyDeviceToHost, st));
+  } else {
+    uint32_t n_per_win = p.half, logL = p.logL0, chunks = p.T0;
+    int rb = 0;
     if constexpr (TE)
-      HIP_OK(LaunchTe::bucket_reduce(false, ctx->red_a[rb].as<XyzzDev>(), ctx->red_x[rb].as<XyzzDev>(), n_per_win, logL, chunks,
-                                     p.bucket_windows, ctx->red_a[rb ^ 1].as<XyzzDev>(), ctx->red_x[rb ^ 1].as<XyzzDev>(), flags, st));
+      HIP_OK(LaunchTe::bucket_reduce(true, nullptr, ctx->buckets.as<XyzzDev>(), n_per_win, logL, chunks, p.bucket_windows,
+                                     ctx->red_a[0].as<XyzzDev>(), ctx->red_x[0].as<XyzzDev>(), flags, st));
     else
-      HIP_OK(Launch<E>::bucket_reduce(false, ctx->red_a[rb].as<XyzzDev>(), ctx->red_x[rb].as<XyzzDev>(), n_per_win, logL, chunks,
-                                      p.bucket_windows, ctx->red_a[rb ^ 1].as<XyzzDev>(), ctx->red_x[rb ^ 1].as<XyzzDev>(), st));
-    rb ^= 1;
+      HIP_OK(Launch<E>::bucket_reduce(true, nullptr, ctx->buckets.as<XyzzDev>(), n_per_win, logL, chunks, p.bucket_windows,
+                                      ctx->red_a[0].as<XyzzDev>(), ctx->red_x[0].as<XyzzDev>(), st));
+    while (chunks > 1) {
+      n_per_win = chunks;
+      logL = p.logL;
+      chunks = ceil_div(n_per_win, 1u << logL);
+      if constexpr (TE)
+        HIP_OK(LaunchTe::bucket_reduce(false, ctx->red_a[rb].as<XyzzDev>(), ctx->red_x[rb].as<XyzzDev>(), n_per_win, logL, chunks,
+                                       p.bucket_windows, ctx->red_a[rb ^ 1].as<XyzzDev>(), ctx->red_x[rb ^ 1].as<XyzzDev>(), flags, st));
+      else
+        HIP_OK(Launch<E>::bucket_reduce(false, ctx->red_a[rb].as<XyzzDev>(), ctx->red_x[rb].as<XyzzDev>(), n_per_win, logL, chunks,
+                                        p.bucket_windows, ctx->red_a[rb ^ 1].as<XyzzDev>(), ctx->red_x[rb ^ 1].as<XyzzDev>(), st));
+      rb ^= 1;
+    }
+    HIP_OK(hipEventRecord(ctx->ev[5], st));
+    HIP_OK(hipMemcpyAsync(ctx->pinned, ctx->red_a[rb].p, p.bucket_windows * sizeof(XyzzDev), hipMemcpyDeviceToHost, st));
   }
-  HIP_OK(hipEventRecord(ctx->ev[5], st));
-  HIP_OK(hipMemcpyAsync(ctx->pinned, ctx->red_a[rb].p, p.bucket_windows * sizeof(XyzzDev), hipMemcpyDeviceToHost, st));
   if constexpr (TE) {
     HIP_OK(hipMemcpyAsync(ctx->h_flags, flags, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     HIP_OK(hipMemsetAsync(flags + 1, 0, sizeof(uint32_t), st));
@@ -998,6 +1048,9 @@ RustError mi355_msm_set_option(mi355_msm_ctx* ctx, const char* key, long value) 
     } else if (k == "reduce_log_chunk") {
       if (value < 0 || value > 7) bad_arg("reduce_log_chunk %ld out of range [1, 7]", value);
       ctx->opt_reduce_log_chunk = value;
+    } else if (k == "reduce_scan") {
+      if (value < -1 || value > 1) bad_arg("reduce_scan %ld out of range [-1, 1]", value);
+      ctx->opt_reduce_scan = value;
     } else if (k == "reduce_log_chunk0") {
       if (value < 0 || value > 7) bad_arg("reduce_log_chunk0 %ld out of range [1, 7]", value);
       ctx->opt_reduce_log_chunk0 = value;

@@ -359,6 +359,48 @@ __global__ void __launch_bounds__(256, G::ACC_WAVES) k_bucket_reduce(const XyzzD
 }
 
 // ------------------------------------------------------------------------------------------------
+// Bucket -> window reduction for SMALL windows (<= 4096 buckets), as a parallel scan: the chunked running sums above are
+// work-efficient but ~80 full additions deep at 2^16 pairs, and a lone wave needs ~10 us per addition -- the bucket
+// reduction was 40 % of a small MSM.  Here every step is ONE addition per thread:
+//   suffix scan   S_j <- S_j + S_(j+d),  d = 1, 2, 4, ...        after log2(nb) steps  S_j = sum_(b >= j) B_b
+//   tree          S_j <- S_j + S_(j+h),  h = nb/2, nb/4, ..., 1   after log2(nb) steps  S_0 = sum_j S_j = sum_b (b+1) B_b
+// 2 log2(nb) launches (22 at 2^16) of n log n work in total, which is nothing at these sizes.
+// mode 0: scan step (all j, partner j + d if it exists); mode 1: tree step (j < d, partner j + d).
+// Larger windows first run ONE level of the chunked scheme (k_bucket_reduce<FIRST>: chunk t of L buckets -> A_t, X_t with
+// V = sum_t A_t + sum_t t X_t), which leaves <= 4096 chunks per window; the scan then runs on the X_t, and
+// mode 2 joins the two sums: out_j = (j == 0 ? identity : S_j) + A_j   (sum_t t X_t = sum_(j >= 1) S_j), a tree finishes.
+template <class G>
+__global__ void __launch_bounds__(256, G::ACC_WAVES) k_reduce_scan_step(const XyzzDevT<typename G::T>* __restrict__ in,
+                                                                        const XyzzDevT<typename G::T>* __restrict__ in2,
+                                                                        XyzzDevT<typename G::T>* __restrict__ out, uint32_t nb, uint32_t windows,
+                                                                        uint32_t d, uint32_t mode, uint32_t* __restrict__ flags) {
+  using E = typename G::E;
+  using XD = XyzzDevT<typename G::T>;
+  const uint32_t span = mode == 1 ? d : nb;
+  const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+  if (g >= windows * span) return;
+  typename E::Md md;
+  const uint32_t w = g / span, j = g % span;
+  const XD* row = in + (size_t)w * nb;
+  XyzzT<typename G::T> r = row[j].p;
+  if (G::is_empty(r) || (mode == 2 && j == 0)) G::set_identity(r);     // (a bucket nobody wrote is all zero)
+  bool bad = false;
+  if (mode == 2) {
+    const XD v = in2[(size_t)w * nb + j];
+    G::add(r, v.p, md);
+    if (G::CHECKS) bad = G::failed(r);
+  } else if (j + d < nb) {
+    const XD v = row[j + d];
+    G::add(r, v.p, md);
+    if (G::CHECKS) bad = G::failed(r);
+  }
+  XD o;
+  o.p = r;
+  out[(size_t)w * nb + j] = o;
+  if (G::CHECKS && bad) flags[1] = 1;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Fixed-base precompute (row f1): table level w holds 2^(c w) * P_i as affine points, so every digit of a scalar feeds
 // ONE shared bucket set and the bucket->window reduction and the Horner fold shrink by the number of windows
 // (CMB PrecomputePoints.cu:10-39 builds 2^(46k) P the same way; P1A matter-labs/src/lib.rs:101-114).

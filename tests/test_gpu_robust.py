@@ -103,3 +103,32 @@ def test_two_fallbacks_in_a_row_demote_the_context(ea, oracle):
     ctx.set_bases(ea.generate_points(n, distinct=100, seed=3))
     assert ctx.query("twisted_edwards") == 1
     ctx.close()
+
+
+@pytest.mark.parametrize("curve,cid", [("bls12_377_g1", 0), ("bls12_381_g1", 1), ("bls12_377_g2", 2)])
+def test_scan_and_chunked_bucket_reductions_agree(ea, oracle, curve, cid):
+    """Small windows reduce their buckets by a parallel scan (one addition per thread and step), large ones by chunked running
+    sums; "reduce_scan" forces either.  Same bytes, also with empty buckets, a single bucket per window and sparse windows."""
+    import ctypes
+
+    stride = ea.affine_stride(curve)
+    # window_bits <= 13: the scan runs on the buckets directly; 14 and 17: one chunked level first, then scan + join + tree
+    for n, wb in ((1, 2), (37, 2), (500, 5), (3000, 9), (20000, 13), (4097, 0), (20000, 14), (5000, 17)):
+        if cid == 2 and n > 5000:
+            continue
+        bases = ea.generate_points(n, distinct=max(1, n // 7), seed=n, curve=curve)
+        sc = _scalars(n, n + wb)
+        sc[:, 31] &= 0x0F
+        if n > 10:
+            sc[3] = 0
+            sc[4, 1:] = 0          # a small scalar: upper windows stay empty
+        exp = ctypes.create_string_buffer(ea.projective_bytes(curve))
+        assert oracle.oracle_msm(cid, bases.ctypes.data, stride, sc.ctypes.data, n, exp, 0) == 0
+        ctx = ea.MultiScalarMultContext(curve)
+        if wb:
+            ctx.set_option("window_bits", wb)
+        ctx.set_bases(bases)
+        for mode in (0, 1, -1):
+            ctx.set_option("reduce_scan", mode)
+            assert ctx.run(sc)[0] == exp.raw, (curve, n, wb, mode)
+        ctx.close()

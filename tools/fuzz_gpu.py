@@ -17,7 +17,7 @@ rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 bad = 0
 for case in range(cases):
     name, cid, top = CURVES[rng.choice([0, 0, 1, 1, 2])]
-    n = rng.choice([1, 2, 5, 31, 32, 33, 100, 257, 1023, 1024, 3000, 9999, 40000])
+    n = rng.choice([1, 2, 5, 31, 32, 33, 100, 257, 1023, 1024, 3000, 8191, 8193, 9999, 40000, 70001, 200000])
     if cid == 2:
         n = min(n, 3000)
     stride = ea.affine_stride(name)
@@ -52,8 +52,9 @@ for case in range(cases):
         limbs[:, 3] %= np.uint64(top)
     # kind 5: full 256-bit scalars (exact integer semantics; the oracle follows arkworks which windows all 256 bits for these c)
     sc = limbs.view(np.uint8).reshape(n, 32)
-    ctx = ea.MultiScalarMultContext(name)
-    opts = {}
+    shards = rng.choice([0, 0, 0, 2, 5])     # 0: ordinary context; else that many logical shards behind the C ABI
+    ctx = ea.MultiScalarMultContext(name, devices=[0] * shards) if shards else ea.MultiScalarMultContext(name)
+    opts = {"shards": shards} if shards else {}
     if rng.random() < 0.3:
         opts["precompute"] = 1
     if rng.random() < 0.5:
@@ -61,7 +62,8 @@ for case in range(cases):
     if cid == 0 and rng.random() < 0.25:
         opts["twisted_edwards"] = 0
     for k, v in opts.items():
-        ctx.set_option(k, v)
+        if k != "shards":
+            ctx.set_option(k, v)
     ctx.set_bases(torch.from_numpy(bases).cuda() if rng.random() < 0.5 else bases)
     if rng.random() < 0.5:
         ctx.set_option("lane_entries", rng.choice([1, 3, 8, 64, 1000])); opts["lane"] = 1
@@ -69,6 +71,8 @@ for case in range(cases):
         ctx.set_option("seg_entries", rng.choice([4, 6, 33]))
     if rng.random() < 0.3:
         ctx.set_option("max_chunk", rng.choice([211, 4096]))
+    if rng.random() < 0.15:
+        ctx.set_option("mem_limit", rng.choice([1 << 20, 16 << 20])); opts["mem_limit"] = 1
     got = ctx.run(torch.from_numpy(sc).cuda() if rng.random() < 0.5 else sc)[0]
     ctx.close()
     out = ctypes.create_string_buffer(ea.projective_bytes(name))
