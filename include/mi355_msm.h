@@ -115,8 +115,10 @@ RustError mi355_msm_run_device(mi355_msm_ctx* ctx, void* out_projective, const v
  * of a scalar share one bucket set and the bucket->window reduction and the window fold shrink by the number of windows --
  * the fixed-base trick of the ZPrize winners (CMB PrecomputePoints.cu:10-39; P1A matter-labs/src/lib.rs:101-114), paid for in
  * the untimed init and in HBM (windows x 128 B per base: 94 GB at 2^26).  Results are identical.
- * Tuning knobs ("window_bits" 2..24, "lane_entries", "max_chunk" <= 2^27, "seg_entries" >= 4, "reduce_log_chunk" 1..7); 0 restores
- * the automatic choice.
+ * Tuning knobs ("window_bits" 2..24, "lane_entries", "max_chunk" <= 2^27, "seg_entries" >= 4, "reduce_log_chunk" /
+ * "reduce_log_chunk0" 1..7: bucket-reduction chunk sizes on all / the first level); 0 restores the automatic choice.
+ * "reduce_scan" = 0 keeps the bucket reduction on the recursive chunked scheme only (default: its tail is a parallel scan).
+ * Test hooks: "mem_limit" (bytes of device memory chunks may be planned against), "inject_alloc_failures".
  * "scalars_montgomery" = 1 makes every run treat the scalars as arkworks `Fr` values (Montgomery form, a*2^256 mod r)
  * and convert them on the device first -- VariableBaseMSM::msm(bases, &[Fr]) = into_bigint + msm_bigint
  * (ARK ec/src/msm/variable_base/mod.rs:48-53; sppark's `mont` flag SPK msm/pippenger.cuh:157-164).
