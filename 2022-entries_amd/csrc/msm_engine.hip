@@ -222,9 +222,11 @@ struct mi355_msm_ctx {
     p.reduce_scan = opt_reduce_scan != 0;
     p.scan_direct = p.reduce_scan && p.half <= 4096;
     if (p.reduce_scan && !p.scan_direct) {
-      const uint32_t need = ilog2_floor(p.half) - 12;
-      if (p.logL0 < need) p.logL0 = need;
-      if (p.logL0 > 9) p.reduce_scan = false;   // (windows beyond 2^21 buckets: keep the recursive scheme)
+      const uint32_t need = ilog2_floor(p.half) - 12;   // first-level chunk size that leaves 4096 chunks
+      if (need > 9)
+        p.reduce_scan = false;   // windows beyond 2^21 buckets (precomputed tables): keep the recursive scheme and ITS chunk sizes
+      else if (p.logL0 < need)
+        p.logL0 = need;
     }
     p.T0 = ceil_div(p.half, 1u << p.logL0);
     return p;
