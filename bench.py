@@ -258,7 +258,7 @@ def main():
                                        f"{'RCCL all-gather' if ctx.query('rccl_exchanges') else 'host fold'} of {args.gpus} partial points" if c_sharded else
                                        f"{world} disjoint base/scalar slices + all-gather of {world} partial points")},
             "stage_ms_per_step": {k: v / args.steps for k, v in stage_ms.items()},
-            "roofline": {"bound": "hbm", "kernel": "k_accumulate" if cid == 2 else "k_accumulate_coop", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "k_accumulate_glds", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_from": traffic_from,
                          "kernel_ms": kern_s * 1e3, "algorithmic_bytes_per_launch": BYTES_PER_PAIR[cid] * pairs_per_launch,
                          "valu": valu,
