@@ -128,7 +128,10 @@ struct Fp2El {
   static MSM_HD void zero(T& r) { fe_zero(r.c0); fe_zero(r.c1); }
   // ABI images: c0 | c1, 12 u32 words each (arkworks QuadExtField { c0, c1 })
   static constexpr int WORDS = 24;
-  static constexpr int ACC_WAVES = 1;   // an Fp2 XYZZ accumulator alone is 112 VGPRs: take the whole 512-entry file
+#ifndef MSM_G2_ACC_WAVES
+#define MSM_G2_ACC_WAVES 1
+#endif
+  static constexpr int ACC_WAVES = MSM_G2_ACC_WAVES;   // an Fp2 XYZZ accumulator alone is 112 VGPRs: take the whole 512-entry file
   static constexpr bool PREFETCH_BASE = false;
   static MSM_HD void from_abi(T& r, const uint32_t* w, const Md& md) {
     fe_from_abi<F>(r.c0, w, md);

@@ -74,6 +74,9 @@ inline PartPlan part_plan(uint32_t n, uint32_t c, uint32_t windows, bool shared,
   while ((2ull << lg) <= (uint64_t)n) lg++;                 // floor(log2 n) for n >= 1
   const uint32_t by_size = lg > 15 ? lg - 15 : 0;
   p.hb = std::min<uint32_t>(std::min<uint32_t>(bits, (uint32_t)PART_MAX_HB), by_size);
+  // ... but the bits it leaves must fit the low half of an entry's key word (the bin rides in the high half while an entry is
+  // staged in LDS): a small input with a large forced window would otherwise leave up to 23
+  if (bits - p.hb > 15) p.hb = bits - 15;
   p.lb = bits - p.hb;
   p.b1 = 1u << p.hb;
   p.nbins = windows * p.b1;
@@ -89,16 +92,21 @@ inline PartPlan part_plan(uint32_t n, uint32_t c, uint32_t windows, bool shared,
   return p;
 }
 
-// Bits taken by each generic pass after level 1: as few passes as possible, at most PART_MAX_RB bits each, split evenly.
+// Bits taken by each generic pass after level 1: as few passes as possible, at most PART_MAX_RB bits each.  The LAST pass takes
+// as many bits as it may and the earlier ones share the rest: a pass costs per SEGMENT it is given (a block per sub-job), so
+// the pass that fans out widest must come last -- 6 + 6 bits at c = 22 left 426 K segments of 2 K entries to the second pass
+// (19 ms); 2 + 10 leaves it 26 K segments of 32 K entries.
 // Always at least one pass (it is the pass that writes the full key into the entries), possibly over zero bits.
 inline int part_pass_bits(uint32_t lb, uint32_t (&rb)[4]) {
   int np = (int)((lb + PART_MAX_RB - 1) / PART_MAX_RB);
   if (np == 0) np = 1;
-  uint32_t left = lb;
-  for (int i = 0; i < np; i++) {
-    rb[i] = (left + (uint32_t)(np - i) - 1) / (uint32_t)(np - i);
+  uint32_t last = lb < (uint32_t)PART_MAX_RB ? lb : (uint32_t)PART_MAX_RB;
+  uint32_t left = lb - last;
+  for (int i = 0; i < np - 1; i++) {
+    rb[i] = (left + (uint32_t)(np - 1 - i) - 1) / (uint32_t)(np - 1 - i);
     left -= rb[i];
   }
+  rb[np - 1] = last;
   return np;
 }
 

@@ -132,3 +132,21 @@ def test_scan_and_chunked_bucket_reductions_agree(ea, oracle, curve, cid):
             ctx.set_option("reduce_scan", mode)
             assert ctx.run(sc)[0] == exp.raw, (curve, n, wb, mode)
         ctx.close()
+
+
+@pytest.mark.parametrize("precompute", [0, 1])
+def test_large_forced_windows_on_small_inputs(ea, oracle, precompute):
+    """window_bits up to 24 on inputs of a few thousand pairs: the grouping then has far more bucket bits than entries to
+    tell apart (two generic passes, level 1 must leave <= 15 bits for the key word's low half) -- results must not care."""
+    n = 3000
+    bases = ea.generate_points(n, distinct=211, seed=12)
+    sc = _scalars(n, 77)
+    exp = oracle_msm_np(oracle, 0, bases, sc, n)
+    for wb in (17, 20, 21, 22, 24):
+        ctx = ea.MultiScalarMultContext("bls12_377_g1")
+        ctx.set_option("window_bits", wb)
+        ctx.set_option("precompute", precompute)
+        ctx.set_bases(bases)
+        assert ctx.run(sc)[0] == exp, (wb, precompute)
+        assert ctx.last_timings()["window_bits"] == wb
+        ctx.close()

@@ -58,7 +58,7 @@ for case in range(cases):
     if rng.random() < 0.3:
         opts["precompute"] = 1
     if rng.random() < 0.5:
-        opts["window_bits"] = rng.randrange(2, 18)
+        opts["window_bits"] = rng.randrange(2, 25) if rng.random() < 0.3 else rng.randrange(2, 18)
     if cid == 0 and rng.random() < 0.25:
         opts["twisted_edwards"] = 0
     for k, v in opts.items():
