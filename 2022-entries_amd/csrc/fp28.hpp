@@ -152,17 +152,35 @@ MSM_HD void mad_chain(uint64_t& col, const uint32_t (&x)[NL], const uint32_t (&y
 #endif
 }
 
+// ~x & LMASK in one instruction (v_bfi_b32 D = (S0 & S1) | (~S0 & S2) with S1 = 0): hipcc would emit v_not + v_and
+MSM_HD uint32_t not_and_lmask(uint32_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  uint32_t d;
+  asm("v_bfi_b32 %0, %1, 0, %2" : "=v"(d) : "v"(x), "s"(LMASK));
+  return d;
+#else
+  return ~x & LMASK;
+#endif
+}
+
 // The Montgomery step of column k: col += m_k * p_0 (which clears the low limb), then shift the column down.
 // When p = 1 (mod 2^28) -- BLS12-377, whose p - 1 is divisible by 2^46 -- m_k = -col mod 2^28 and p_0 = 1, so
-// (col + m_k) >> 28 = (col + 2^28 - 1) >> 28: one 64-bit add instead of a multiply-add (126 fewer per mixed addition).
+// (col + m_k) >> 28 = (col + 2^28 - 1) >> 28: one 64-bit add instead of a multiply-add (126 fewer per mixed addition), and
+// m_k itself falls out of that sum: with s = col + 2^28 - 1,  ~s = -col - 2^28  (mod 2^32), so m_k = ~s & (2^28 - 1) --
+// three instructions per column (v_lshl_add_u64, v_bfi_b32, v_lshrrev_b64) instead of four.
+// MK_FROM_COL: the caller has not computed m_k yet (the p_0 = 1 path derives it here; otherwise it is (col * M0) & LMASK).
 #define MSM_MONT_STEP(F, col, mk, md)                                              \
   do {                                                                             \
     if (F::P[0] == 1) {                                                            \
+      const uint64_t s_ = (col) + LMASK;                                           \
+      (mk) = not_and_lmask((uint32_t)s_);                                          \
+      MSM_CHECK((mk) == ((0u - (uint32_t)(col)) & LMASK));                         \
       MSM_CHECK_COL_ADD(mk);                                                       \
       MSM_CHECK_COL_END((col) + (mk));                                             \
-      MSM_CHECK((((col) + (mk)) & LMASK) == 0 && (((col) + (mk)) >> LB) == (((col) + LMASK) >> LB)); \
-      (col) = ((col) + LMASK) >> LB;                                               \
+      MSM_CHECK((((col) + (mk)) & LMASK) == 0 && (((col) + (mk)) >> LB) == (s_ >> LB)); \
+      (col) = s_ >> LB;                                                            \
     } else {                                                                       \
+      (mk) = ((uint32_t)(col) * F::M0) & LMASK;                                    \
       (col) += (uint64_t)(mk) * (md).p[0];                                         \
       MSM_CHECK_COL_ADD((unsigned __int128)(mk) * (md).p[0]);                      \
       MSM_CHECK_COL_END(col);                                                      \
@@ -200,7 +218,6 @@ MSM_HD void fe_mul(Fe& r, const Fe& a, const Fe& b, const Modulus<F>& md) {
       MSM_CHECK_COL_ADD((unsigned __int128)m[i] * md.p[k - i]);
     }
     mad_chain<true>(col, xs, ys, k);
-    m[k] = ((uint32_t)col * F::M0) & LMASK;
     MSM_MONT_STEP(F, col, m[k], md);
   }
 #pragma unroll
@@ -266,7 +283,6 @@ MSM_HD void fe_mul2(Fe& r, const Fe& a, const Fe& b, const Fe& c, const Fe& d, c
       MSM_CHECK_COL_ADD((unsigned __int128)m[i] * md.p[k - i]);
     }
     mad_chain<true>(col, xs, ys, k);
-    m[k] = ((uint32_t)col * F::M0) & LMASK;
     MSM_MONT_STEP(F, col, m[k], md);
   }
 #pragma unroll
@@ -339,7 +355,6 @@ MSM_HD void fe_sqr(Fe& r, const Fe& a, const Modulus<F>& md) {
       MSM_CHECK_COL_ADD((unsigned __int128)m[i] * md.p[k - i]);
     }
     mad_chain<true>(col, xs, ys, k);
-    m[k] = ((uint32_t)col * F::M0) & LMASK;
     MSM_MONT_STEP(F, col, m[k], md);
   }
 #pragma unroll
