@@ -41,6 +41,18 @@ struct FpEl {
   static MSM_HD void mul(T& r, const T& a, const T& b, const Md& md) { fe_mul<F>(r, a, b, md); }
   static MSM_HD void sqr(T& r, const T& a, const Md& md) { fe_sqr<F>(r, a, md); }
   static MSM_HD void mul2(T& r, const T& a, const T& b, const T& c, const T& d, const Md& md) { fe_mul2<F>(r, a, b, c, d, md); }
+  // The *_c forms take operands whose limbs are already carried (see Fp2El, where that saves most of the bookkeeping);
+  // over Fp the plain multiplier accepts lazy limbs anyway, so they are the same functions and prep() is a no-op.
+  template <bool B_BIG>
+  static MSM_HD void mul_c(T& r, const T& a, const T& b, const Md& md) { fe_mul<F>(r, a, b, md); }
+  static MSM_HD void sqr_c(T& r, const T& a, const Md& md) { fe_sqr<F>(r, a, md); }
+  static MSM_HD void prep(T&) {}
+  // r = a*b - c*d, class M;  d class M
+  static MSM_HD void mul_sub_c(T& r, const T& a, const T& b, const T& c, const T& d, const Md& md) {
+    T nd;
+    fe_neg(nd, d, F::BIAS2_28);   // -d as (0, 2p], limbs < 2^29
+    fe_mul2<F>(r, a, b, c, nd, md);
+  }
   static MSM_HD void add(T& r, const T& a, const T& b) { fe_add(r, a, b); }
   static MSM_HD void dbl(T& r, const T& a) { fe_dbl(r, a); }
   static MSM_HD void sub(T& r, const T& a, const T& b, const uint32_t (&bias)[NL]) { fe_sub(r, a, b, bias); }
@@ -111,6 +123,45 @@ struct Fp2El {
     mul(t2, c, d, md);
     fe_add(r.c0, t1.c0, t2.c0);            // < 3p, limbs < 2^29: fine as a stored coordinate
     fe_add(r.c1, t1.c1, t2.c1);
+    fe_carry(r.c0);
+    fe_carry(r.c1);
+  }
+  // The same product for operands that are already CARRIED (limbs < 2^28 + 16), which is what the group law's hot path
+  // holds anyway: no carries, no weak reduction.  The BETA factor moves to the a side, the sign to the b side:
+  //   c0 = a0 b0 + (5 a1)(K p - b1),   K p = BIAS2_28 for a class-M b (strictly normalized, < 2p), BIAS32_29 (B_BIG) for a
+  //   carried b of value <= 18p.  Column bound of the fused product: 14 (2^56 + 1.25 * 2^30 * 1.5 * 2^29 + 2^56) < 0.93 * 2^64;
+  //   value: (18p 18p + 90p 32p) / 2^15 p + p < 2p -- class M as ever.
+  template <bool B_BIG>
+  static MSM_HD void mul_c(T& r, const T& a, const T& b, const Md& md) {
+    Fe s, nb, c0, c1;
+#pragma unroll
+    for (int i = 0; i < NL; i++) s.v[i] = a.c1.v[i] * (uint32_t)NEG_BETA;
+    if (B_BIG) fe_neg(nb, b.c1, F::BIAS32_29); else fe_neg(nb, b.c1, F::BIAS2_28);
+    fe_mul2<F>(c0, a.c0, b.c0, s, nb, md);
+    fe_mul2<F>(c1, a.c0, b.c1, a.c1, b.c0, md);
+    r.c0 = c0;
+    r.c1 = c1;
+  }
+  // (a0 + a1 u)^2 = (a0^2 + BETA a1^2) + (2 a0 a1) u: the u part is ONE product, not two.  a carried, value <= 18p.
+  static MSM_HD void sqr_c(T& r, const T& a, const Md& md) {
+    Fe s, nb, d, c0, c1;
+#pragma unroll
+    for (int i = 0; i < NL; i++) s.v[i] = a.c1.v[i] * (uint32_t)NEG_BETA;
+    fe_neg(nb, a.c1, F::BIAS32_29);
+    fe_mul2<F>(c0, a.c0, a.c0, s, nb, md);
+    fe_dbl(d, a.c1);                       // limbs < 2^29 + 32
+    fe_mul<F>(c1, a.c0, d, md);
+    r.c0 = c0;
+    r.c1 = c1;
+  }
+  static MSM_HD void prep(T& a) { fe_carry(a.c0); fe_carry(a.c1); }
+  // r = a*b - c*d as a stored coordinate (limbs < 2^28 + 16, value < 4p);  a, b, c carried (b of value <= 18p), d class M
+  static MSM_HD void mul_sub_c(T& r, const T& a, const T& b, const T& c, const T& d, const Md& md) {
+    T t1, t2;
+    mul_c<true>(t1, a, b, md);
+    mul_c<false>(t2, c, d, md);
+    fe_sub(r.c0, t1.c0, t2.c0, F::BIAS2_28);
+    fe_sub(r.c1, t1.c1, t2.c1, F::BIAS2_28);
     fe_carry(r.c0);
     fe_carry(r.c1);
   }
@@ -243,26 +294,24 @@ MSM_HD void xyzz_from_affine(XyzzT<typename E::T>& r, const AffineT<typename E::
   E::set_one(r.zzz);
 }
 
-// Shared tail of madd/add:  given P, R, PP = P^2 (already known non-zero mod p), the "first" point's
-// U1 (=X1 for madd) and S1 (=Y1), produce X3, Y3 and return PPP for the ZZ/ZZZ updates.
+// Tail of the full addition:  given P (carried), R, PP = P^2 (already known non-zero mod p), the first point's U1 and S1
+// (class M), produce X3, Y3 and return PPP for the ZZ/ZZZ updates.
 //   X3 = R^2 - PPP - 2Q,  Y3 = R (Q - X3) - S1 PPP,  Q = U1 PP.
 template <class E>
 MSM_HD void add_tail(typename E::T& x3, typename E::T& y3, typename E::T& ppp, const typename E::T& P, typename E::T& R, const typename E::T& PP, const typename E::T& U1, const typename E::T& S1,
                      const typename E::Md& md) {
-  typename E::T q, r2, t, d, nppp;
-  E::mul(ppp, P, PP, md);   // M
-  E::mul(q, U1, PP, md);    // M
-  E::carry(R);                 // limbs < 2^28 + 16 (value unchanged): lets R share a reduction below
-  E::sqr(r2, R, md);        // M
+  typename E::T q, r2, t, d;
+  E::template mul_c<false>(ppp, P, PP, md);   // M
+  E::template mul_c<false>(q, U1, PP, md);    // M
+  E::carry(R);                 // limbs < 2^28 + 16 (value unchanged)
+  E::sqr_c(r2, R, md);         // M
   E::dbl(t, q);                // < 4p, limbs < 2^29
   E::add(t, t, ppp);           // < 6p, limbs < 3*2^28
   E::sub(x3, r2, t, E::Fld::BIAS8_30);  // (2p, 10p), limbs < 2^28 + 2^30 + 2^28
   E::carry(x3);                // limbs < 2^28 + 16
   E::sub(d, q, x3, E::Fld::BIAS16_29);  // (6p, 18p), limbs < 2^30
   E::carry(d);                 // limbs < 2^28 + 16
-  E::neg(nppp, ppp, E::Fld::BIAS2_28);  // -PPP as (0, 2p], limbs < 2^29
-  // Y3 = R*D - S1*PPP = R*D + S1*(-PPP): one reduction for both products; the result is class M
-  E::mul2(y3, R, d, S1, nppp, md);
+  E::mul_sub_c(y3, R, d, S1, ppp, md);  // Y3 = R*D - S1*PPP (over Fp: one reduction for both products)
 }
 
 // acc = 2 * (x2, y2) from affine coordinates (mdbl-2008-s-1).  y2 may be a negated (lazy) value with
@@ -293,64 +342,100 @@ MSM_HD void xyzz_dbl_affine(XyzzT<typename E::T>& acc, const typename E::T& x2, 
 // acc = 2 * acc (dbl-2008-s-1).
 template <class E>
 MSM_HD void xyzz_dbl(XyzzT<typename E::T>& acc, const typename E::Md& md) {
-  typename E::T u, v, w, s, xx, m, mm, t, d, nw, y1 = acc.y;
+  typename E::T u, v, w, s, xx, m, mm, t, d, y1 = acc.y;
   E::dbl(u, acc.y);            // limbs < 2^29 + 32, value < 32p
-  E::sqr(v, u, md);
-  E::mul(w, u, v, md);
-  E::mul(s, acc.x, v, md);
-  E::sqr(xx, acc.x, md);
+  E::prep(u);
+  E::sqr_c(v, u, md);
+  E::template mul_c<false>(w, u, v, md);
+  E::template mul_c<false>(s, acc.x, v, md);
+  E::sqr_c(xx, acc.x, md);
   E::dbl(m, xx);
-  E::add(m, m, xx);
+  E::add(m, m, xx);            // 3*XX: < 6p, limbs < 3*2^28
   E::carry(m);
-  E::sqr(mm, m, md);
+  E::sqr_c(mm, m, md);
   E::dbl(t, s);
   E::sub(acc.x, mm, t, E::Fld::BIAS4_29);
   E::carry(acc.x);
-  E::sub(d, s, acc.x, E::Fld::BIAS8_29);
+  E::sub(d, s, acc.x, E::Fld::BIAS8_29);   // (2p, 10p), limbs < 2^30
   E::carry(d);
-  E::neg(nw, w, E::Fld::BIAS2_28);
-  E::mul2(acc.y, m, d, y1, nw, md);
-  E::mul(acc.zz, v, acc.zz, md);
-  E::mul(acc.zzz, w, acc.zzz, md);
+  E::mul_sub_c(acc.y, m, d, y1, w, md);    // M*(S - X3) - Y1*W
+  E::template mul_c<false>(acc.zz, v, acc.zz, md);
+  E::template mul_c<false>(acc.zzz, w, acc.zzz, md);
 }
 
-// acc += (+/-)(x2, y2)   (madd-2008-s; 8M + 2S on the common path).
+// The rare half of a mixed addition: acc and (+/-)(x2, y2) have the same x, so the sum is either the double of the point or
+// infinity (SPK ec/xyzz_t.hpp:214-236 handles the same two cases inline).
+template <class E>
+MSM_HD void xyzz_madd_same_x(XyzzT<typename E::T>& acc, const AffineT<typename E::T>& p, bool negate, const typename E::Md& md) {
+  typename E::T y2, ny, s2, R, r2;
+  E::neg(ny, p.y, E::Fld::BIAS2_28);
+  y2 = p.y;
+  E::cmov(y2, ny, negate);
+  E::mul(s2, y2, acc.zzz, md);
+  E::sub(R, s2, acc.y, E::Fld::BIAS16_29);
+  E::sqr(r2, R, md);
+  if (E::is_zero_M(r2)) {
+    xyzz_dbl_affine<E>(acc, p.x, y2, md);
+  } else {
+    xyzz_set_inf<E>(acc);
+  }
+}
+
+// acc += (+/-)(x2, y2)   (madd-2008-s; 8M + 2S), the common path only: returns true -- with acc untouched -- when the two
+// points share their x coordinate and xyzz_madd_same_x must finish the job.  The split exists for the accumulate kernel:
+// the rare branch would otherwise keep both base coordinates alive across the whole addition (56 VGPRs on G2); the kernel
+// re-reads the base from memory instead when it happens.
 // `acc_inf` lets the caller pass what it already knows (a fresh run starts at infinity) so the common
 // first-element case costs no field work.  The affine point must not be infinity (filtered upstream:
 // the digit kernel emits no entries for bases flagged infinite).
+// The order of the operations is chosen for register pressure (an Fp2 element is 28 VGPRs): every old coordinate dies as
+// early as it can.
 template <class E>
-MSM_HD void xyzz_madd(XyzzT<typename E::T>& acc, const AffineT<typename E::T>& p, bool negate, bool acc_inf, const typename E::Md& md) {
+MSM_HD bool xyzz_madd_common(XyzzT<typename E::T>& acc, const AffineT<typename E::T>& p, bool negate, bool acc_inf, const typename E::Md& md) {
   if (acc_inf || xyzz_is_inf<E>(acc)) {
     xyzz_from_affine<E>(acc, p, negate);
-    return;
+    return false;
   }
-  typename E::T y2, ny;
-  E::neg(ny, p.y, E::Fld::BIAS2_28);  // limbs < 2^29 + 2^28... (bias limb < 2^29) -> < 2^30
+  // Operand classes: p.x, ZZ, ZZZ, PP, PPP are class M; X1, Y1 are stored coordinates (carried limbs); P, y2, R, D are
+  // brought to carried limbs by prep()/carry() -- which is all the *_c multipliers ask for.
+  typename E::T u2, P, PP;
+  E::template mul_c<false>(u2, p.x, acc.zz, md);
+  E::sub(P, u2, acc.x, E::Fld::BIAS16_29);  // (0, 18p), limbs < 2^30
+  E::prep(P);
+  E::sqr_c(PP, P, md);
+  if (E::is_zero_M(PP)) return true;
+  typename E::T y2, ny, s2, R;
+  E::neg(ny, p.y, E::Fld::BIAS2_28);         // (0, 2p], limbs < 2^29
   y2 = p.y;
   E::cmov(y2, ny, negate);
-  typename E::T u2, s2, P, R, PP;
-  E::mul(u2, p.x, acc.zz, md);
-  E::mul(s2, y2, acc.zzz, md);
-  E::sub(P, u2, acc.x, E::Fld::BIAS16_29);  // (0, 18p), limbs < 2^30
+  E::prep(y2);
+  E::template mul_c<false>(s2, y2, acc.zzz, md);
   E::sub(R, s2, acc.y, E::Fld::BIAS16_29);
-  E::sqr(PP, P, md);
-  if (E::is_zero_M(PP)) {
-    // same x: either the same point (double) or its negative (infinity).
-    typename E::T r2;
-    E::sqr(r2, R, md);
-    if (E::is_zero_M(r2)) {
-      xyzz_dbl_affine<E>(acc, p.x, y2, md);
-    } else {
-      xyzz_set_inf<E>(acc);
-    }
-    return;
-  }
-  typename E::T x3, y3, ppp;
-  add_tail<E>(x3, y3, ppp, P, R, PP, acc.x, acc.y, md);
-  acc.x = x3;
+  E::carry(R);                               // limbs < 2^28 + 16 (value unchanged, <= 18p)
+  E::template mul_c<false>(acc.zz, acc.zz, PP, md);     // old ZZ dies
+  typename E::T ppp, q;
+  E::template mul_c<false>(ppp, P, PP, md);             // P dies
+  E::template mul_c<false>(q, acc.x, PP, md);           // old X and PP die
+  E::template mul_c<false>(acc.zzz, acc.zzz, ppp, md);  // old ZZZ dies
+  // X3 = R^2 - PPP - 2Q,  Y3 = R (Q - X3) - Y1 PPP
+  typename E::T r2, t, d;
+  E::sqr_c(r2, R, md);
+  E::dbl(t, q);                              // < 4p, limbs < 2^29
+  E::add(t, t, ppp);                         // < 6p, limbs < 3*2^28
+  E::sub(acc.x, r2, t, E::Fld::BIAS8_30);    // (2p, 10p), limbs < 2^28 + 2^30 + 2^28
+  E::carry(acc.x);                           // limbs < 2^28 + 16
+  E::sub(d, q, acc.x, E::Fld::BIAS16_29);    // (6p, 18p), limbs < 2^30
+  E::carry(d);                               // limbs < 2^28 + 16
+  typename E::T y3;
+  E::mul_sub_c(y3, R, d, acc.y, ppp, md);    // over Fp: one reduction for both products
   acc.y = y3;
-  E::mul(acc.zz, acc.zz, PP, md);
-  E::mul(acc.zzz, acc.zzz, ppp, md);
+  return false;
+}
+
+// acc += (+/-)(x2, y2), every case.
+template <class E>
+MSM_HD void xyzz_madd(XyzzT<typename E::T>& acc, const AffineT<typename E::T>& p, bool negate, bool acc_inf, const typename E::Md& md) {
+  if (xyzz_madd_common<E>(acc, p, negate, acc_inf, md)) xyzz_madd_same_x<E>(acc, p, negate, md);
 }
 
 // acc += b   (add-2008-s; 12M + 2S).
@@ -362,13 +447,14 @@ MSM_HD void xyzz_add(XyzzT<typename E::T>& acc, const XyzzT<typename E::T>& b, c
     return;
   }
   typename E::T u1, u2, s1, s2, P, R, PP;
-  E::mul(u1, acc.x, b.zz, md);
-  E::mul(u2, b.x, acc.zz, md);
-  E::mul(s1, acc.y, b.zzz, md);
-  E::mul(s2, b.y, acc.zzz, md);
+  E::template mul_c<false>(u1, acc.x, b.zz, md);
+  E::template mul_c<false>(u2, b.x, acc.zz, md);
+  E::template mul_c<false>(s1, acc.y, b.zzz, md);
+  E::template mul_c<false>(s2, b.y, acc.zzz, md);
   E::sub(P, u2, u1, E::Fld::BIAS2_28);  // (0, 4p), limbs < 3*2^28
   E::sub(R, s2, s1, E::Fld::BIAS2_28);
-  E::sqr(PP, P, md);
+  E::prep(P);
+  E::sqr_c(PP, P, md);
   if (E::is_zero_M(PP)) {
     typename E::T r2;
     E::sqr(r2, R, md);
@@ -383,10 +469,10 @@ MSM_HD void xyzz_add(XyzzT<typename E::T>& acc, const XyzzT<typename E::T>& b, c
   add_tail<E>(x3, y3, ppp, P, R, PP, u1, s1, md);
   acc.x = x3;
   acc.y = y3;
-  E::mul(t, acc.zz, b.zz, md);
-  E::mul(acc.zz, t, PP, md);
-  E::mul(t, acc.zzz, b.zzz, md);
-  E::mul(acc.zzz, t, ppp, md);
+  E::template mul_c<false>(t, acc.zz, b.zz, md);
+  E::template mul_c<false>(acc.zz, t, PP, md);
+  E::template mul_c<false>(t, acc.zzz, b.zzz, md);
+  E::template mul_c<false>(acc.zzz, t, ppp, md);
 }
 
 }  // namespace msm

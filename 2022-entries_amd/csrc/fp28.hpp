@@ -256,7 +256,10 @@ MSM_HD void fe_mul2(Fe& r, const Fe& a, const Fe& b, const Fe& c, const Fe& d, c
   uint64_t col = 0;
 #pragma unroll
   for (int i = 0; i < NL; i++) {
-    MSM_CHECK(a.v[i] < (1u << 29) && b.v[i] < (1u << 29) && c.v[i] < (1u << 29) && d.v[i] < (1u << 29));
+    // (or: c up to 5 * (2^28 + 16) against d < 2^29 + 2^28 when a, b are carried -- Fp2El::mul_c; the column checks below
+    //  hold the exact sums against 2^64 either way)
+    MSM_CHECK((a.v[i] < (1u << 29) && b.v[i] < (1u << 29) && c.v[i] < (1u << 29) && d.v[i] < (1u << 29)) ||
+              (a.v[i] < (1u << 28) + 16 && b.v[i] < (1u << 28) + 16 && c.v[i] < 5 * ((1u << 28) + 16) && d.v[i] < (3u << 28)));
   }
   // (two separately unrolled halves: one 27-trip loop is only partially unrolled by hipcc and then indexes
   //  registers dynamically)

@@ -60,7 +60,9 @@ struct SwLaw {
   static MSM_HD void madd(XyzzT<T>& acc, const Base& b, bool negate, bool fresh, const Md& md) { xyzz_madd<E>(acc, b, negate, fresh, md); }
   // k_accumulate_glds: a lane's record as it lies in LDS (sector c at rec + c * rs) -> registers; madd_loaded consumes it
   static MSM_HD void load_sectors(Base& p, const unsigned char* rec, int rs, bool /*negate*/) { copy_record_sectors(p, rec, rs); }
-  static MSM_HD void madd_loaded(XyzzT<T>& acc, const Base& b, bool negate, bool fresh, const Md& md) { xyzz_madd<E>(acc, b, negate, fresh, md); }
+  // true = same x: the caller re-reads the base (from_dev) and calls madd_same_x
+  static MSM_HD bool madd_loaded(XyzzT<T>& acc, const Base& b, bool negate, bool fresh, const Md& md) { return xyzz_madd_common<E>(acc, b, negate, fresh, md); }
+  static MSM_HD void madd_same_x(XyzzT<T>& acc, const Base& b, bool negate, const Md& md) { xyzz_madd_same_x<E>(acc, b, negate, md); }
   static MSM_HD void add(XyzzT<T>& acc, const XyzzT<T>& b, const Md& md) { xyzz_add<E>(acc, b, md); }
   static MSM_HD void mul_pow2(XyzzT<T>& acc, uint32_t k, const Md& md) {
     if (xyzz_is_inf<E>(acc)) return;
@@ -101,7 +103,11 @@ struct TeLaw {
     copy_fe_sector(p.ypx, rec + o1);
     copy_fe_sector(p.td, rec + 2 * rs);
   }
-  static MSM_HD void madd_loaded(Xyzz& acc, const Base& b, bool negate, bool /*fresh*/, const Md& md) { te_madd<F, true>(acc, b, negate, md); }
+  static MSM_HD bool madd_loaded(Xyzz& acc, const Base& b, bool negate, bool /*fresh*/, const Md& md) {
+    te_madd<F, true>(acc, b, negate, md);
+    return false;   // the law is complete: no exceptional pairs
+  }
+  static MSM_HD void madd_same_x(Xyzz&, const Base&, bool, const Md&) {}
   // Z = 0 never occurs in a valid point: it marks an empty (zero-filled) bucket, which adds nothing.
   static MSM_HD void add(Xyzz& acc, const Xyzz& b, const Md& md) {
     if (fe_is_zero_M<F>(b.zz)) return;

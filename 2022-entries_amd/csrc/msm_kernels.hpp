@@ -255,7 +255,11 @@ __global__ void __launch_bounds__(256, G::ACC_WAVES) k_accumulate_glds(const uin
         fresh = true;
         G::begin_run(acc);
       }
-      G::madd_loaded(acc, p, (val >> 31) != 0, fresh, md);
+      if (G::madd_loaded(acc, p, (val >> 31) != 0, fresh, md)) {
+        // exceptional pair (short Weierstrass only): the record in LDS is already being overwritten, so fetch it again
+        const Base again = G::from_dev(bases[val & IDX_MASK]);
+        G::madd_same_x(acc, again, (val >> 31) != 0, md);
+      }
       if (G::CHECKS) bad |= G::failed(acc);
       fresh = false;
     }
