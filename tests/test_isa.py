@@ -64,6 +64,14 @@ def test_accumulate_kernel_isa(law):
     if law == "te":
         # Y - X and Y + X are read from each other's sector for a negated base: per-lane LDS addresses, 14 selects left (2dXY)
         assert ops.count("v_cndmask_b32_e64") <= 24 and res["vgprs"] <= 168      # 3 waves/SIMD resident
+        # p = 1 mod 2^28: the Montgomery step of a low column is v_lshl_add_u64 + v_bfi_b32 + v_lshrrev_b64 (fp28.hpp
+        # MSM_MONT_STEP) -- 14 per multiplication, 7 multiplications; the rest of the VALU stream is bounded below
+        assert ops.count("v_bfi_b32") == 98, ops.count("v_bfi_b32")
+        valu = [o for o in ops if o.startswith("v_")]
+        assert len(valu) - mads <= 960, len(valu) - mads     # whole kernel (static count), prologue and flushes included
+    else:
+        # the common path of the mixed addition keeps neither base coordinate alive (curve.hpp xyzz_madd_common): 3 waves/SIMD
+        assert res["vgprs"] <= 168, res["vgprs"]
     # selects are emitted in the VOP3 form: back-to-back v_cndmask_b32_e32 (mask implicit in VCC) issue at 22.9 cycles in isolation
     # against 4.2 for v_cndmask_b32_e64 (profiles/r02_ubench_valu_w4.txt).  In this kernel the difference did not show
     # (profiles/r02_ab_cndmask.txt); the form is pinned anyway so that a scheduling change cannot bring the slow case back
