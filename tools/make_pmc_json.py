@@ -13,6 +13,10 @@ sys.path.insert(0, ROOT)
 from bench import kernel_source_sha16  # noqa: E402
 
 prof = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "prof")
+# optional: <out json> <windows> <npow> <window bits> <config text> -- for a second workload (G2: profiles/r02_pmc_k_accumulate_g2.json)
+out_json = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles", "r02_pmc_k_accumulate.json")
+W_, NPOW_, C_ = (int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])) if len(sys.argv) > 5 else (13, 26, 20)
+config_text = sys.argv[6] if len(sys.argv) > 6 else None
 
 
 def headline_counters(tag):
@@ -40,9 +44,9 @@ for f in glob.glob(os.path.join(prof, "stats", "**", "*kernel_trace.csv"), recur
          if "k_accumulate" in r["Kernel_Name"] and int(r["Grid_Size_X"]) == c.get("lanes")]
     if d:
         kern_ms = sum(d) / len(d)
-entries = 13 * (1 << 26) * (1 - 2.0 ** -20)     # non-zero digits at c = 20, 13 windows
+entries = W_ * (1 << NPOW_) * (1 - 2.0 ** -C_)     # non-zero digits (c = 20, 13 windows at 2^26)
 res = {
-    "config": "bls12_377_g1 npow=26 (c = 20, 13 windows), the k_accumulate_glds<TeLaw> launch of a bench step: twisted-Edwards image, "
+    "config": config_text or "bls12_377_g1 npow=26 (c = 20, 13 windows), the k_accumulate_glds<TeLaw> launch of a bench step: twisted-Edwards image, "
               "LDS-DMA quad-cooperative gathers of 192-B records, (value, key) entry stream",
     "source": "tools/profile_gpu.sh: rocprofv3 --kernel-trace --pmc ..., one counter group per pass; summary in profiles/r02_rocprof_summary.txt",
     "kernel_source_sha16": kernel_source_sha16(),
@@ -61,5 +65,5 @@ if c.get("SQ_INSTS_VALU"):
     res["derived"]["valu_instr_per_mixed_add"] = c["SQ_INSTS_VALU"] * 64 / entries
 if c.get("SQ_ACTIVE_INST_VALU") and c.get("GRBM_GUI_ACTIVE"):
     res["derived"]["valu_busy_fraction"] = c["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / (c["GRBM_GUI_ACTIVE"] / 8)
-json.dump(res, open(os.path.join(ROOT, "profiles", "r02_pmc_k_accumulate.json"), "w"), indent=1)
+json.dump(res, open(out_json, "w"), indent=1)
 print(json.dumps(res, indent=1))
