@@ -117,6 +117,15 @@ inline uint32_t ilog2_floor(uint64_t v) { uint32_t r = 0; while (v >>= 1) r++; r
 // only ever receives the signed-digit carry (about half of the scalars).  Buckets exist for all ceil(257/c) windows (any 256-bit
 // scalar is legal), or for ONE window when precomputed tables let all digits share a bucket set.
 int choose_window_bits(size_t n, int scalar_bits, bool shared_buckets) {
+  // Between 2^12 and 2^19 pairs an MSM is latency, not throughput: what a window size costs is the launches it implies
+  // (two scan steps of the bucket reduction per bit, a grouping pass more from 12 bits on, per-window steps of the level-1
+  // tiles) and the model below does not see them.  Measured on all three curves (tools/small_c_sweep.py,
+  // profiles/r02_small_c_sweep.txt): c = 8 up to ~2^15.5 and c = 11 up to 2^18 (2^17 for 255-bit scalars) are 4-14 % faster
+  // than the model's choice (9..14).
+  if (!shared_buckets && n > ((size_t)1 << 12)) {
+    if (n < ((size_t)3 << 14)) return 8;
+    if (n < ((size_t)3 << (scalar_bits > 253 ? 16 : 17))) return 11;
+  }
   int best = 2;
   double best_cost = 1e300;
   for (int c = 2; c <= (shared_buckets ? 24 : 23); c++) {

@@ -83,7 +83,7 @@ MSM_HD void te_tail(Xyzz& r, const Fe& A, const Fe& B, const Fe& C, const Fe& D,
 }
 
 // acc += (+/-) base   (7M).  -(X, Y) = (-X, Y): Y - X and Y + X trade places and 2dXY changes sign.
-// SWAPPED = the caller has already exchanged ymx / ypx of a negated base (k_accumulate_coop does it with the LDS read
+// SWAPPED = the caller has already exchanged ymx / ypx of a negated base (k_accumulate_glds does it with the LDS read
 // addresses); only the sign of 2dXY is left to apply.
 template <class F, bool SWAPPED = false>
 MSM_HD void te_madd(Xyzz& acc, const TeAffine& b, bool negate, const Modulus<F>& md) {
