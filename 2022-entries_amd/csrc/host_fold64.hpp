@@ -5,7 +5,9 @@
 // inversion were 0.4-0.5 ms per MSM -- half the wall time of a small MSM.  The same arithmetic on 64-bit limbs (CIOS with
 // 128-bit products, fully reduced) is ~4x faster.  This is the part every reference entry also leaves on the host
 // (SPK msm/pippenger.cuh:556-614, CMB yrrid-ff-ec/HostReduce.cpp:61-78); the formulas are the public EFD ones used in
-// curve.hpp / te.hpp, re-stated for canonical values.  G1 only (G2 keeps the generic path).
+// curve.hpp / te.hpp, re-stated for canonical values.  The short-Weierstrass functions are generic over the coordinate
+// field: Fp64 for G1, Fp2_64 (Fp2 over it) for G2 -- whose fold of 37 windows on the device representation was 1.7 ms, as long
+// as the whole device side of a small G2 MSM.
 //
 // Values are Montgomery residues with R = 2^384 -- exactly the ABI's representation, so results need no conversion.
 #pragma once
@@ -21,6 +23,8 @@ struct F64 {
 };
 
 struct Fp64 {
+  using El = F64;
+  static constexpr int COORD_BYTES = 48;
   uint64_t p[6];
   uint64_t inv;      // -p^-1 mod 2^64
   F64 one;           // R mod p
@@ -123,6 +127,8 @@ struct Fp64 {
     r = acc;
   }
 
+  const F64& one_el() const { return one; }
+  void store(uint8_t* out, const F64& a) const { memcpy(out, a.l, 48); }
   // device field element (any bounded lazy value) -> F64
   template <class F>
   void from_device(F64& r, const Fe& a) const {
@@ -176,17 +182,91 @@ struct Fp64 {
   }
 };
 
-struct Xyzz64 {
-  F64 x, y, zz, zzz;
+// Fp2 = Fp[u] / (u^2 + NEG_BETA) over an Fp64 (NEG_BETA = 5 for BLS12-377: ARKC bls12_377/src/fields/fq2.rs:13), ABI image c0 | c1.
+struct F2_64 {
+  F64 c0, c1;
 };
 
-// ---- short Weierstrass (a = 0), XYZZ: dbl-2008-s-1 and add-2008-s, canonical values ------------------------------------
-inline bool sw64_is_inf(const Fp64& f, const Xyzz64& a) { return f.is_zero(a.zz); }
-inline void sw64_set_inf(Xyzz64& a) { memset(&a, 0, sizeof a); }
+template <int NEG_BETA>
+struct Fp2_64 {
+  using El = F2_64;
+  static constexpr int COORD_BYTES = 96;
+  const Fp64* f;
+  void add(El& r, const El& a, const El& b) const { f->add(r.c0, a.c0, b.c0); f->add(r.c1, a.c1, b.c1); }
+  void sub(El& r, const El& a, const El& b) const { f->sub(r.c0, a.c0, b.c0); f->sub(r.c1, a.c1, b.c1); }
+  void dbl(El& r, const El& a) const { f->dbl(r.c0, a.c0); f->dbl(r.c1, a.c1); }
+  bool is_zero(const El& a) const { return f->is_zero(a.c0) && f->is_zero(a.c1); }
+  void times_neg_beta(F64& r, const F64& a) const {   // small constant: by additions
+    F64 acc = a;
+    for (int i = 1; i < NEG_BETA; i++) f->add(acc, acc, a);
+    r = acc;
+  }
+  // (a0 + a1 u)(b0 + b1 u) = (a0 b0 - NB a1 b1) + ((a0 + a1)(b0 + b1) - a0 b0 - a1 b1) u   (quadratic_extension.rs:641-652)
+  void mul(El& r, const El& a, const El& b) const {
+    F64 t0, t1, t2, sa, sb;
+    f->mul(t0, a.c0, b.c0);
+    f->mul(t1, a.c1, b.c1);
+    f->add(sa, a.c0, a.c1);
+    f->add(sb, b.c0, b.c1);
+    f->mul(t2, sa, sb);
+    f->sub(t2, t2, t0);
+    f->sub(r.c1, t2, t1);
+    times_neg_beta(t1, t1);
+    f->sub(r.c0, t0, t1);
+  }
+  void sqr(El& r, const El& a) const {
+    F64 t0, t1, t2;
+    f->mul(t0, a.c0, a.c0);
+    f->mul(t1, a.c1, a.c1);
+    f->mul(t2, a.c0, a.c1);
+    f->dbl(r.c1, t2);
+    times_neg_beta(t1, t1);
+    f->sub(r.c0, t0, t1);
+  }
+  // 1 / (a0 + a1 u) = (a0 - a1 u) / (a0^2 + NB a1^2)
+  void invert(El& r, const El& a) const {
+    F64 n, t, ni;
+    f->mul(n, a.c0, a.c0);
+    f->mul(t, a.c1, a.c1);
+    times_neg_beta(t, t);
+    f->add(n, n, t);
+    f->invert(ni, n);
+    f->mul(r.c0, a.c0, ni);
+    f->mul(t, a.c1, ni);
+    f->neg(r.c1, t);
+  }
+  El one_el() const {
+    El o{};
+    o.c0 = f->one;
+    return o;
+  }
+  void store(uint8_t* out, const El& a) const {
+    memcpy(out, a.c0.l, 48);
+    memcpy(out + 48, a.c1.l, 48);
+  }
+  template <class F>
+  void from_device(El& r, const Fe2& a) const {
+    f->template from_device<F>(r.c0, a.c0);
+    f->template from_device<F>(r.c1, a.c1);
+  }
+};
 
-inline void sw64_dbl(const Fp64& f, Xyzz64& a) {
+template <class El>
+struct XyzzG64 {
+  El x, y, zz, zzz;
+};
+using Xyzz64 = XyzzG64<F64>;
+
+// ---- short Weierstrass (a = 0), XYZZ: dbl-2008-s-1 and add-2008-s, canonical values; FC = Fp64 or Fp2_64 ----------------
+template <class FC>
+inline bool sw64_is_inf(const FC& f, const XyzzG64<typename FC::El>& a) { return f.is_zero(a.zz); }
+template <class El>
+inline void sw64_set_inf(XyzzG64<El>& a) { memset(&a, 0, sizeof a); }
+
+template <class FC>
+inline void sw64_dbl(const FC& f, XyzzG64<typename FC::El>& a) {
   if (sw64_is_inf(f, a)) return;
-  F64 u, v, w, s, m, t, x3, y3;
+  typename FC::El u, v, w, s, m, t, x3, y3;
   f.dbl(u, a.y);
   f.sqr(v, u);
   f.mul(w, u, v);
@@ -207,13 +287,14 @@ inline void sw64_dbl(const Fp64& f, Xyzz64& a) {
   f.mul(a.zzz, w, a.zzz);
 }
 
-inline void sw64_add(const Fp64& f, Xyzz64& a, const Xyzz64& b) {
+template <class FC>
+inline void sw64_add(const FC& f, XyzzG64<typename FC::El>& a, const XyzzG64<typename FC::El>& b) {
   if (sw64_is_inf(f, b)) return;
   if (sw64_is_inf(f, a)) {
     a = b;
     return;
   }
-  F64 u1, u2, s1, s2, P, R, PP, PPP, Q, t, x3, y3;
+  typename FC::El u1, u2, s1, s2, P, R, PP, PPP, Q, t, x3, y3;
   f.mul(u1, a.x, b.zz);
   f.mul(u2, b.x, a.zz);
   f.mul(s1, a.y, b.zzz);
@@ -247,38 +328,39 @@ inline void sw64_add(const Fp64& f, Xyzz64& a, const Xyzz64& b) {
 }
 
 // XYZZ -> ABI Projective image, normalised: (x, y, 1) or (1, 1, 0)
-inline void sw64_to_abi(const Fp64& f, uint8_t* out, const Xyzz64& a) {
-  F64 x = f.one, y = f.one, z{};
+template <class FC>
+inline void sw64_to_abi(const FC& f, uint8_t* out, const XyzzG64<typename FC::El>& a) {
+  typename FC::El x = f.one_el(), y = f.one_el(), z{};
   if (!sw64_is_inf(f, a)) {
-    F64 t, ti, zzi, zzzi;
+    typename FC::El t, ti, zzi, zzzi;
     f.mul(t, a.zz, a.zzz);
     f.invert(ti, t);
     f.mul(zzi, ti, a.zzz);
     f.mul(zzzi, ti, a.zz);
     f.mul(x, a.x, zzi);
     f.mul(y, a.y, zzzi);
-    z = f.one;
+    z = f.one_el();
   }
-  memcpy(out, x.l, 48);
-  memcpy(out + 48, y.l, 48);
-  memcpy(out + 96, z.l, 48);
+  f.store(out, x);
+  f.store(out + FC::COORD_BYTES, y);
+  f.store(out + 2 * FC::COORD_BYTES, z);
 }
 
-template <class F>
-inline void xyzz64_from_device(const Fp64& f, Xyzz64& r, const Xyzz& a) {
-  f.from_device<F>(r.x, a.x);
-  f.from_device<F>(r.y, a.y);
-  f.from_device<F>(r.zz, a.zz);
-  f.from_device<F>(r.zzz, a.zzz);
+template <class F, class FC, class DevEl>
+inline void xyzz64_from_device(const FC& f, XyzzG64<typename FC::El>& r, const XyzzT<DevEl>& a) {
+  f.template from_device<F>(r.x, a.x);
+  f.template from_device<F>(r.y, a.y);
+  f.template from_device<F>(r.zz, a.zz);
+  f.template from_device<F>(r.zzz, a.zzz);
 }
 
 // result = sum_w 2^(c w) sums[w]   (Horner, high to low)
-template <class F>
-inline void fold_windows64(const Fp64& f, Xyzz64& acc, const Xyzz* sums, int windows, int c) {
+template <class F, class FC, class DevEl>
+inline void fold_windows64(const FC& f, XyzzG64<typename FC::El>& acc, const XyzzT<DevEl>* sums, int windows, int c) {
   sw64_set_inf(acc);
   for (int w = windows - 1; w >= 0; w--) {
     for (int i = 0; i < c; i++) sw64_dbl(f, acc);
-    Xyzz64 s;
+    XyzzG64<typename FC::El> s;
     xyzz64_from_device<F>(f, s, sums[w]);
     sw64_add(f, acc, s);
   }

@@ -351,20 +351,37 @@ extern "C" int ht_f64_op(int curve, int op, const uint8_t* a, const uint8_t* b, 
 // Window sums S_w = k_w * P_w (affine images + 64-bit multipliers) folded with window size c, both ways; the two Projective
 // images go to out_generic / out_fold64.  te = 1 (BLS12-377 only): the sums live on the twisted-Edwards image.
 // Returns 0, or 2 when an Edwards addition hit a vanishing denominator (both implementations must agree on that too).
+template <class E>
+struct Fold64Of;   // the 64-bit field object that mirrors a device coordinate field
+template <class F>
+struct Fold64Of<FpEl<F>> {
+  static const Fp64& get() { return test_fp64<F>(); }
+};
+template <class F, int NB>
+struct Fold64Of<Fp2El<F, NB>> {
+  static const Fp2_64<NB>& get() {
+    static const Fp2_64<NB> f{&test_fp64<F>()};
+    return f;
+  }
+};
+
 template <class C>
 static int t_fold_both(const uint8_t* pts, size_t stride, const uint64_t* mult, int windows, int c, int te, uint8_t* out_generic,
                        uint8_t* out_fold64) {
   using E = typename C::E;
   using F = typename E::Fld;
+  using El = typename E::T;
   typename E::Md md;
-  const Fp64& f = test_fp64<F>();
-  Xyzz sums[64];
+  const auto& f = Fold64Of<E>::get();
+  using FC = std::decay_t<decltype(f)>;
+  constexpr size_t PB = 3 * 4 * E::WORDS;   // bytes of a Projective image
+  XyzzT<El> sums[64];
   if (windows > 64) return 1;
   for (int w = 0; w < windows; w++) {
-    Affine a;
+    AffineT<El> a;
     const bool inf = affine_from_abi<E>(a, pts + (size_t)w * stride, md);
     if (te) {
-      if constexpr (std::is_same<F, Bls12_377_Fq>::value) {
+      if constexpr (std::is_same<E, FpEl<Bls12_377_Fq>>::value) {
         te_set_identity<F>(sums[w]);
         if (!inf) {
           TeAffine t;
@@ -385,12 +402,14 @@ static int t_fold_both(const uint8_t* pts, size_t stride, const uint64_t* mult, 
       }
     }
   }
-  Xyzz g;
-  Xyzz64 h;
+  XyzzT<El> g;
+  XyzzG64<typename FC::El> h;
   bool ok_g = true, ok_h = true;
   if (te) {
-    ok_g = fold_windows_te<F>(g, sums, windows, c, md);
-    ok_h = fold_windows_te64<F>(f, h, sums, windows, c);
+    if constexpr (std::is_same<E, FpEl<Bls12_377_Fq>>::value) {
+      ok_g = fold_windows_te<F>(g, sums, windows, c, md);
+      ok_h = fold_windows_te64<F>(f, h, sums, windows, c);
+    }
   } else {
     fold_windows<E>(g, sums, windows, c, md);
     fold_windows64<F>(f, h, sums, windows, c);
@@ -400,17 +419,18 @@ static int t_fold_both(const uint8_t* pts, size_t stride, const uint64_t* mult, 
   xyzz_to_projective_abi<E>(out_generic, g, md);
   sw64_to_abi(f, out_fold64, h);
   // the chunk sum as well: h + h against the generic doubling
-  Xyzz64 hh = h;
+  XyzzG64<typename FC::El> hh = h;
   sw64_add(f, hh, h);
-  Xyzz gg = g;
+  XyzzT<El> gg = g;
   xyzz_add<E>(gg, g, md);
-  uint8_t b1[144], b2[144];
+  uint8_t b1[PB], b2[PB];
   xyzz_to_projective_abi<E>(b1, gg, md);
   sw64_to_abi(f, b2, hh);
-  return memcmp(b1, b2, 144) == 0 ? 0 : 4;
+  return memcmp(b1, b2, PB) == 0 ? 0 : 4;
 }
 extern "C" int ht_fold_both(int curve, const uint8_t* pts, size_t stride, const uint64_t* mult, int windows, int c, int te,
                             uint8_t* out_generic, uint8_t* out_fold64) {
   if (curve == 1) return te ? 1 : t_fold_both<Bls12_381_G1>(pts, stride, mult, windows, c, 0, out_generic, out_fold64);
+  if (curve == 2) return te ? 1 : t_fold_both<Bls12_377_G2>(pts, stride, mult, windows, c, 0, out_generic, out_fold64);
   return t_fold_both<Bls12_377_G1>(pts, stride, mult, windows, c, te, out_generic, out_fold64);
 }

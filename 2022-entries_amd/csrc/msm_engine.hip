@@ -213,10 +213,13 @@ struct mi355_msm_ctx {
     p.half = 1u << (p.c - 1);
     p.keybits = ilog2_floor(p.bucket_windows * p.half) + 1;   // bits of a bucket key (reported by mi355_msm_plan)
     p.entries = (uint64_t)p.windows * n;
-    uint32_t K = opt_lane_entries ? (uint32_t)opt_lane_entries : (uint32_t)std::min<uint64_t>(256, std::max<uint64_t>(8, p.entries >> 20));
+    // entries per accumulate lane: 2^20 lanes at full size; below that fewer, longer lanes win until the chip would go idle
+    // (tools/small_k_sweep.py: 24 instead of 8 at 2^17..2^19 pairs: -4..-11 % wall; 36..64 instead of 18..36 at 2^20..2^21: -3 %)
+    const uint64_t k_auto = std::max<uint64_t>({p.entries >= (3u << 20) ? 24u : 8u, p.entries >> 20, std::min<uint64_t>(64, p.entries >> 19)});
+    uint32_t K = opt_lane_entries ? (uint32_t)opt_lane_entries : (uint32_t)std::min<uint64_t>(256, k_auto);
     p.K = (K + 3) & ~3u;
     p.nlanes = ceil_div(p.entries, p.K);
-    p.segK = opt_seg_entries >= 4 ? (uint32_t)opt_seg_entries : 8;
+    p.segK = opt_seg_entries >= 4 ? (uint32_t)opt_seg_entries : (p.entries < (2u << 20) ? 4 : 8);   // small inputs: shallower levels (-1..-3 %)
     uint64_t nb = (uint64_t)p.bucket_windows * p.half;
     uint32_t l0 = nb > (1u << 18) ? ilog2_floor(nb >> 18) : 0;
     // chunks of 4 on the later (small, latency-bound) levels and on small inputs: -7 % wall at 2^14..2^18 against chunks of 8
@@ -422,7 +425,7 @@ void set_bases_device(mi355_msm_ctx* ctx, const void* d_affine, size_t n, size_t
 }
 
 // ---- the host tail (window fold, chunk sums, normalisation) -----------------------------------------------------------
-// G1: on 64-bit limbs (host_fold64.hpp, ~4x faster than the device representation run on a CPU core); G2: the generic code.
+// On 64-bit limbs (host_fold64.hpp, ~4x faster than the device representation run on a CPU core), G1 and G2 alike.
 template <class F>
 const Fp64& fp64_of() {
   static const Fp64 ctx = [] {
@@ -438,22 +441,21 @@ const Fp64& fp64_of() {
   return ctx;
 }
 
+template <class F, int NB>
+const Fp2_64<NB>& fp2_64_of() {
+  static const Fp2_64<NB> ctx{&fp64_of<F>()};
+  return ctx;
+}
+
 template <class E>
-struct HostTail {   // generic (G2): the device representation, host_curve.hpp
-  using Pt = XyzzT<typename E::T>;
-  static void set_inf(Pt& a) { xyzz_set_inf<E>(a); }
-  static void add(Pt& a, const Pt& b) {
-    typename E::Md md;
-    xyzz_add<E>(a, b, md);
-  }
-  static void fold(Pt& out, const Pt* sums, int windows, int c) {
-    typename E::Md md;
-    fold_windows<E>(out, sums, windows, c, md);
-  }
-  static void to_abi(uint8_t* out, const Pt& a) {
-    typename E::Md md;
-    xyzz_to_projective_abi<E>(out, a, md);
-  }
+struct HostTail;
+template <class F, int NB>
+struct HostTail<Fp2El<F, NB>> {   // G2: the same code over Fp2
+  using Pt = XyzzG64<F2_64>;
+  static void set_inf(Pt& a) { sw64_set_inf(a); }
+  static void add(Pt& a, const Pt& b) { sw64_add(fp2_64_of<F, NB>(), a, b); }
+  static void fold(Pt& out, const XyzzT<Fe2>* sums, int windows, int c) { fold_windows64<F>(fp2_64_of<F, NB>(), out, sums, windows, c); }
+  static void to_abi(uint8_t* out, const Pt& a) { sw64_to_abi(fp2_64_of<F, NB>(), out, a); }
 };
 template <class F>
 struct HostTail<FpEl<F>> {
