@@ -467,6 +467,23 @@ struct HostTail<FpEl<F>> {
   static void to_abi(uint8_t* out, const Pt& a) { sw64_to_abi(fp64_of<F>(), out, a); }
 };
 
+// The W window sums (the first element of every window's row) straight into pinned host memory, the two flag words with
+// them, flag 1 re-armed: one tiny kernel instead of a 2-D copy, a copy and a memset -- the runtime's copy path alone left a
+// 22-us hole in the timeline of a small MSM (tools/gap_probe.py).
+__global__ void __launch_bounds__(256) k_collect_sums(const uint4* __restrict__ src, uint32_t row_stride_u4, uint32_t row_u4, uint32_t rows,
+                                                      uint4* __restrict__ dst_host, uint32_t* __restrict__ flags, uint32_t* __restrict__ flags_host) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i < rows * row_u4) {
+    const uint32_t r = i / row_u4, c = i - r * row_u4;
+    dst_host[i] = src[(size_t)r * row_stride_u4 + c];
+  }
+  if (flags_host && i == 0) {
+    flags_host[0] = flags[0];
+    flags_host[1] = flags[1];
+    flags[1] = 0;
+  }
+}
+
 // One chunk of one batch: device scalars [0, n) against bases [base0, base0 + n).  Leaves the folded chunk sum in `out`.
 // TE = true runs the twisted-Edwards kernels (BLS12-377 G1 contexts whose bases all have an image) and returns false when
 // an addition reported a vanishing denominator: the caller then repeats the chunk with TE = false.
@@ -569,6 +586,8 @@ bool run_chunk_impl(mi355_msm_ctx* ctx, const uint32_t* d_scalars, size_t base0,
   HIP_OK(hipEventRecord(ctx->ev[4], st));
 
   // buckets -> one point per window
+  const XyzzDev* sums_src = nullptr;   // where the W window sums end up: element 0 of rows that are sums_stride elements apart
+  uint32_t sums_stride = 1;
   if (p.reduce_scan) {
     // parallel scan, one addition per thread and step.  Direct: on the buckets, ping-pong with a second bucket-sized array.
     // Otherwise: one chunked level first (A_t, X_t per chunk), scan on the X_t, join with the A_t, tree.
@@ -602,8 +621,8 @@ bool run_chunk_impl(mi355_msm_ctx* ctx, const uint32_t* d_scalars, size_t base0,
     if (nb == 1 && !a_sums) step(1, 0);   // a single bucket per window: one pass that normalises an empty bucket to the identity
     HIP_OK(hipEventRecord(ctx->ev[5], st));
     // the window sums sit at the head of each window's row
-    HIP_OK(hipMemcpy2DAsync(ctx->pinned, sizeof(XyzzDev), bufs[cur], (size_t)nb * sizeof(XyzzDev), sizeof(XyzzDev), p.bucket_windows,
-                            hipMemcpyDeviceToHost, st));
+    sums_src = bufs[cur];
+    sums_stride = nb;
   } else {
     uint32_t n_per_win = p.half, logL = p.logL0, chunks = p.T0;
     int rb = 0;
@@ -626,11 +645,15 @@ bool run_chunk_impl(mi355_msm_ctx* ctx, const uint32_t* d_scalars, size_t base0,
       rb ^= 1;
     }
     HIP_OK(hipEventRecord(ctx->ev[5], st));
-    HIP_OK(hipMemcpyAsync(ctx->pinned, ctx->red_a[rb].p, p.bucket_windows * sizeof(XyzzDev), hipMemcpyDeviceToHost, st));
+    sums_src = ctx->red_a[rb].as<XyzzDev>();
+    sums_stride = 1;
   }
-  if constexpr (TE) {
-    HIP_OK(hipMemcpyAsync(ctx->h_flags, flags, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    HIP_OK(hipMemsetAsync(flags + 1, 0, sizeof(uint32_t), st));
+  {
+    static_assert(sizeof(XyzzDev) % 16 == 0, "window sums are collected in 16-byte pieces");
+    const uint32_t row_u4 = sizeof(XyzzDev) / 16, total = p.bucket_windows * row_u4;
+    hipLaunchKernelGGL(k_collect_sums, dim3((total + 255) / 256), dim3(256), 0, st, reinterpret_cast<const uint4*>(sums_src), sums_stride * row_u4, row_u4,
+                       p.bucket_windows, reinterpret_cast<uint4*>(ctx->pinned), TE ? flags : nullptr, TE ? ctx->h_flags : nullptr);
+    HIP_OK(hipGetLastError());
   }
   HIP_OK(hipEventRecord(ctx->ev[6], st));
   // everything for this chunk is enqueued: host work that should hide behind it (the next batch's H2D copy) goes here

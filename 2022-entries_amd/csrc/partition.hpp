@@ -344,7 +344,6 @@ __global__ void __launch_bounds__(PART_THREADS) k_l1_scatter(const uint32_t* __r
   for (uint32_t w = 0; w < w_lo; w++) {
 #pragma unroll
     for (int k = 0; k < PART_PER_THREAD; k++) {
-      if ((uint32_t)k >= kmax) continue;
       uint32_t mag;
       bool neg;
       next_digit(st[k], p.c, p.half, wmask, mag, neg);
@@ -362,8 +361,10 @@ __global__ void __launch_bounds__(PART_THREADS) k_l1_scatter(const uint32_t* __r
     uint2 ent[PART_PER_THREAD];
 #pragma unroll
     for (int k = 0; k < PART_PER_THREAD; k++) {
-      where[k] = 0xffffffffu;
-      if ((uint32_t)k >= kmax) continue;
+      if ((uint32_t)k >= kmax) {
+        where[k] = 0xffffffffu;
+        continue;
+      }
       uint32_t mag;
       bool neg;
       next_digit(st[k], p.c, p.half, wmask, mag, neg);
@@ -371,6 +372,7 @@ __global__ void __launch_bounds__(PART_THREADS) k_l1_scatter(const uint32_t* __r
       bool ok = ((alive >> k) & 1) && mag != 0;
       const uint32_t idx = p.idx0 + i + w * p.table_stride;
       if (ok && p.table_stride) ok = inf[idx] == 0;
+      where[k] = 0xffffffffu;
       const uint32_t bucket = ok ? mag - 1 : 0, hi = bucket >> p.lb;
       uint32_t rank = 0;
       if (few)

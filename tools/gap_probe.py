@@ -20,3 +20,6 @@ for s, e, n in run:
     d = by.setdefault(n, [0, 0.0]); d[0] += 1; d[1] += (e - s) / 1e3
 for n, (c, t) in sorted(by.items(), key=lambda kv: -kv[1][1]):
     print("  %-42s x%-3d %8.1f us  (%.1f us each)" % (n, c, t, t / c))
+big = sorted(((run[i][0] - run[i - 1][1]) / 1e3, run[i - 1][2], run[i][2]) for i in range(1, len(run)))[-4:]
+for g, a, b in reversed(big):
+    print("  gap %.1f us between %s -> %s" % (g, a, b))
