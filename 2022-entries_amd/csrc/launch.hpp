@@ -33,6 +33,8 @@ struct Launch {
 // The twisted-Edwards fast path of BLS12-377 G1 (kernels_377te.hip).  `flags`: [0] += bases without an image (convert),
 // [1] = 1 when an addition hit a vanishing denominator (any walking kernel).
 struct LaunchTe {
+  // launches of at most this many additions use the four-lanes-per-addition kernels (latency), larger ones one lane each (throughput)
+  static uint32_t quad_limit;
   static hipError_t convert(const AffineDev* in, const uint8_t* inf, uint32_t n, uint32_t J, Fe* prefix, TeAffineDev* out, uint32_t* flags,
                             hipStream_t st);
   static hipError_t accumulate(const uint2* entries, const uint32_t* n_real, uint32_t K,

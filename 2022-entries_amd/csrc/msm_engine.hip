@@ -1094,6 +1094,10 @@ RustError mi355_msm_set_option(mi355_msm_ctx* ctx, const char* key, long value) 
     } else if (k == "reduce_log_chunk") {
       if (value < 0 || value > 7) bad_arg("reduce_log_chunk %ld out of range [1, 7]", value);
       ctx->opt_reduce_log_chunk = value;
+    } else if (k == "quad_limit") {
+      // process-wide: launches of at most this many additions run four lanes per addition (twisted-Edwards merge / scan steps)
+      if (value < 0 || value > (1L << 24)) bad_arg("quad_limit %ld out of range [0, 2^24]", value);
+      LaunchTe::quad_limit = (uint32_t)value;
     } else if (k == "reduce_scan") {
       if (value < -1 || value > 1) bad_arg("reduce_scan %ld out of range [-1, 1]", value);
       ctx->opt_reduce_scan = value;

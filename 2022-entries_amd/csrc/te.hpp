@@ -124,6 +124,70 @@ MSM_HD void te_add(Xyzz& acc, const Xyzz& b, const Modulus<F>& md) {
   te_tail<F>(acc, A, B, C, D, md);
 }
 
+#if defined(__HIPCC__)
+// ---- one addition by the four lanes of a quad ------------------------------------------------------------------------
+// Where an MSM is a chain of DEPENDENT additions on a nearly idle chip (the fragment merge and the scan reduction of small and
+// medium inputs: ~14 us per step for a lone wave, 25-40 steps), the 9 multiplications of the unified addition are spread over
+// a quad: lane q holds coordinate q of both operands (0 X, 1 Y, 2 Z, 3 T -- the order they lie in memory) and of the result.
+//   step 1   lane 0: A = (Y1 - X1)(Y2 - X2)   lane 1: B = (Y1 + X1)(Y2 + X2)   lane 2: Z1 Z2   lane 3: k T2
+//   step 2   lane 3: C = T1 (k T2)            (the other lanes idle through it)
+//   step 3   lane 0: X3 = E F   lane 1: Y3 = G H   lane 2: Z3 = F G   lane 3: T3 = E H
+// Three multiplications deep instead of nine; operands travel by DPP quad permutes (X <-> Y between lanes 0 and 1 before
+// step 1, A, B, Z1 Z2, C to every lane before step 3).  Same bounds as te_add / te_tail.  Returns the lane's coordinate of
+// a + b; all four lanes of the quad must call it together.
+template <int CTRL>
+__device__ __forceinline__ void fe_quad_perm(Fe& r, const Fe& a) {
+#pragma unroll
+  for (int i = 0; i < NL; i++) r.v[i] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a.v[i], CTRL, 0xf, 0xf, true);
+}
+__device__ __forceinline__ void fe_select(Fe& r, const Fe& a, const Fe& b, bool take_b) {   // r = take_b ? b : a
+  const LaneMask m = lane_mask(take_b);
+  r = a;
+  fe_cmov(r, b, m);
+}
+
+template <class F>
+__device__ __forceinline__ void te_add_quad(Fe& a, const Fe& b, uint32_t q, const Modulus<F>& md) {
+  Fe pa, pb, u, v, t0, t1;
+  fe_quad_perm<0xB1>(pa, a);                  // lanes 0 <-> 1, 2 <-> 3
+  fe_quad_perm<0xB1>(pb, b);
+  // lane 0 (own X, partner Y): Y - X;  lane 1 (own Y, partner X): Y + X
+  fe_sub(t0, pa, a, F::BIAS2_28);             // (0, 4p), limbs < 2^28 + 2^29
+  fe_add(t1, a, pa);                          // < 4p, limbs < 2^29
+  fe_select(u, t1, t0, q == 0);
+  fe_sub(t0, pb, b, F::BIAS2_28);
+  fe_add(t1, b, pb);
+  fe_select(v, t1, t0, q == 0);
+  // lane 2: Z1, Z2;  lane 3: k, T2
+  Fe k;
+  fe_set(k, Bls12_377_Te::K2D);
+  fe_select(t0, a, k, q == 3);
+  fe_select(u, u, t0, q >= 2);
+  fe_select(v, v, b, q >= 2);
+  Fe r1, r2;
+  fe_mul<F>(r1, u, v, md);                    // A | B | Z1 Z2 | k T2
+  fe_mul<F>(r2, a, r1, md);                   // lane 3: C = T1 (k T2)
+  fe_select(r1, r1, r2, q == 3);
+  Fe A, B, C, D, Z;
+  fe_quad_perm<0x00>(A, r1);
+  fe_quad_perm<0x55>(B, r1);
+  fe_quad_perm<0xAA>(Z, r1);
+  fe_quad_perm<0xFF>(C, r1);
+  fe_dbl(D, Z);                               // < 3p, limbs < 2^29
+  Fe e, f, g, h;
+  fe_sub(e, B, A, F::BIAS2_28);               // as te_tail
+  fe_sub(f, D, C, F::BIAS2_28);
+  fe_add(g, D, C);
+  fe_add(h, B, A);
+  // lane 0: E F   lane 1: G H   lane 2: F G   lane 3: E H
+  fe_select(u, e, g, q == 1);
+  fe_select(u, u, f, q == 2);
+  fe_select(v, h, f, q == 0);
+  fe_select(v, v, g, q == 2);
+  fe_mul<F>(a, u, v, md);
+}
+#endif
+
 template <class F>
 MSM_HD void te_dbl(Xyzz& acc, const Modulus<F>& md) {
   const Xyzz b = acc;
