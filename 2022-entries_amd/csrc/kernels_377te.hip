@@ -10,7 +10,7 @@ using G = TeLaw<Bls12_377_Fq>;
 inline uint32_t te_blocks(uint64_t n) { return (uint32_t)((n + 255) / 256); }
 }  // namespace
 
-uint32_t LaunchTe::quad_limit = 1u << 16;
+uint32_t LaunchTe::quad_limit = 1u << 18;   // tools/quad_limit_sweep.py: flat from 2^16 up, 2^18 best at 2^20 pairs
 
 hipError_t LaunchTe::convert(const AffineDev* in, const uint8_t* inf, uint32_t n, uint32_t J, Fe* prefix, TeAffineDev* out, uint32_t* flags,
                              hipStream_t st) {

@@ -167,7 +167,7 @@ struct mi355_msm_ctx {
   void* pinned = nullptr;  // window sums land here
   size_t pinned_bytes = 0;
   hipEvent_t ev[8] = {};
-  long opt_window_bits = 0, opt_lane_entries = 0, opt_max_chunk = 0, opt_seg_entries = 0, opt_scalars_montgomery = 0;
+  long opt_window_bits = 0, opt_lane_entries = 0, opt_max_chunk = 0, opt_seg_entries = 0, opt_scalars_montgomery = 0, opt_reduce_scan_log = 0;
   long opt_precompute = 0;
   long opt_reduce_log_chunk = 0, opt_reduce_log_chunk0 = 0;
   long opt_reduce_scan = -1;      // 0: recursive chunked running sums only; otherwise the scan tail (default)
@@ -232,9 +232,10 @@ struct mi355_msm_ctx {
     // scan (one addition per thread and step).  Small windows (<= 4096 buckets) scan their buckets directly; larger ones run
     // ONE chunked level that leaves at most 4096 chunks.
     p.reduce_scan = opt_reduce_scan != 0;
-    p.scan_direct = p.reduce_scan && p.half <= 4096;
+    const uint32_t scan_log = opt_reduce_scan_log ? (uint32_t)opt_reduce_scan_log : 12;
+    p.scan_direct = p.reduce_scan && p.half <= (1u << scan_log);
     if (p.reduce_scan && !p.scan_direct) {
-      const uint32_t need = ilog2_floor(p.half) - 12;   // first-level chunk size that leaves 4096 chunks
+      const uint32_t need = ilog2_floor(p.half) - scan_log;   // first-level chunk size that leaves 2^scan_log chunks
       if (need > 9)
         p.reduce_scan = false;   // windows beyond 2^21 buckets (precomputed tables): keep the recursive scheme and ITS chunk sizes
       else if (p.logL0 < need)
@@ -1094,6 +1095,9 @@ RustError mi355_msm_set_option(mi355_msm_ctx* ctx, const char* key, long value) 
     } else if (k == "reduce_log_chunk") {
       if (value < 0 || value > 7) bad_arg("reduce_log_chunk %ld out of range [1, 7]", value);
       ctx->opt_reduce_log_chunk = value;
+    } else if (k == "reduce_scan_log") {
+      if (value != 0 && (value < 6 || value > 18)) bad_arg("reduce_scan_log %ld out of range [6, 18]", value);
+      ctx->opt_reduce_scan_log = value;
     } else if (k == "quad_limit") {
       // process-wide: launches of at most this many additions run four lanes per addition (twisted-Edwards merge / scan steps)
       if (value < 0 || value > (1L << 24)) bad_arg("quad_limit %ld out of range [0, 2^24]", value);

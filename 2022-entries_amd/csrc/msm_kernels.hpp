@@ -411,6 +411,8 @@ __global__ void __launch_bounds__(256, G::ACC_WAVES) k_reduce_scan_step(const Xy
 // it is three multiplications deep.  Lane q of a quad owns coordinate q (X, Y, Z, T: the order of XyzzT in memory) of the
 // operands and of the result.  Same semantics as k_reduce_scan_step / k_segreduce, which stay in charge above
 // LaunchTe::quad_limit additions per launch, where throughput counts (the quad form spends 4/3 of the instructions).
+// (The first chunked level of the bucket reduction -- 53 K chunks of 128 buckets at 2^26 pairs -- looks latency-bound too but
+// is not: a quad per chunk made it 3.0 -> 3.9 ms.)
 __device__ __forceinline__ bool quad_bcast_z(bool z) {   // lane 2's flag (the Z coordinate) to the whole quad
   return __builtin_amdgcn_update_dpp(0, (int)z, 0xAA, 0xf, 0xf, true) != 0;
 }
