@@ -22,11 +22,60 @@ struct F64 {
   uint64_t l[6];
 };
 
+#if defined(__x86_64__)
+// One Montgomery product on BMI2 + ADX (mulx with two independent carry chains, adcx / adox): ~2x the code clang makes of the
+// portable loop below.  The row structure is that of Fp64::mul (no-carry CIOS); the seven accumulator words rotate through
+// r8..r14 so that the shift by one word per row is a renaming.  t = a b R^-1 mod p up to one subtraction of p (the caller does it).
+#define MSM_MONT_ROW(i, t0, t1, t2, t3, t4, t5, t6)                                                   \
+  "movq " #i "*8(%[b]), %%rdx\n\t"                                                                    \
+  "xorq %%rax, %%rax\n\t"                                                                             \
+  "mulxq 0(%[a]), %%rax, %%rbx\n\t adcxq %%rax, %%" #t0 "\n\t adoxq %%rbx, %%" #t1 "\n\t"             \
+  "mulxq 8(%[a]), %%rax, %%rbx\n\t adcxq %%rax, %%" #t1 "\n\t adoxq %%rbx, %%" #t2 "\n\t"             \
+  "mulxq 16(%[a]), %%rax, %%rbx\n\t adcxq %%rax, %%" #t2 "\n\t adoxq %%rbx, %%" #t3 "\n\t"            \
+  "mulxq 24(%[a]), %%rax, %%rbx\n\t adcxq %%rax, %%" #t3 "\n\t adoxq %%rbx, %%" #t4 "\n\t"            \
+  "mulxq 32(%[a]), %%rax, %%rbx\n\t adcxq %%rax, %%" #t4 "\n\t adoxq %%rbx, %%" #t5 "\n\t"            \
+  "mulxq 40(%[a]), %%rax, %%rbx\n\t adcxq %%rax, %%" #t5 "\n\t adoxq %%rbx, %%" #t6 "\n\t"            \
+  "adcxq %[zero], %%" #t6 "\n\t"                                                                      \
+  "movq %%" #t0 ", %%rdx\n\t imulq %[inv], %%rdx\n\t"                                                 \
+  "xorq %%rax, %%rax\n\t"                                                                             \
+  "mulxq 0(%[p]), %%rax, %%rbx\n\t adcxq %%rax, %%" #t0 "\n\t adoxq %%rbx, %%" #t1 "\n\t"             \
+  "mulxq 8(%[p]), %%rax, %%rbx\n\t adcxq %%rax, %%" #t1 "\n\t adoxq %%rbx, %%" #t2 "\n\t"             \
+  "mulxq 16(%[p]), %%rax, %%rbx\n\t adcxq %%rax, %%" #t2 "\n\t adoxq %%rbx, %%" #t3 "\n\t"            \
+  "mulxq 24(%[p]), %%rax, %%rbx\n\t adcxq %%rax, %%" #t3 "\n\t adoxq %%rbx, %%" #t4 "\n\t"            \
+  "mulxq 32(%[p]), %%rax, %%rbx\n\t adcxq %%rax, %%" #t4 "\n\t adoxq %%rbx, %%" #t5 "\n\t"            \
+  "mulxq 40(%[p]), %%rax, %%rbx\n\t adcxq %%rax, %%" #t5 "\n\t adoxq %%rbx, %%" #t6 "\n\t"            \
+  "adcxq %[zero], %%" #t6 "\n\t"
+
+inline void mont_mul_adx(uint64_t* out, const uint64_t* a, const uint64_t* b, const uint64_t* p, uint64_t inv) {
+  static const uint64_t zero = 0;
+  asm volatile(
+      "xorq %%r8, %%r8\n\t xorq %%r9, %%r9\n\t xorq %%r10, %%r10\n\t xorq %%r11, %%r11\n\t xorq %%r12, %%r12\n\t xorq %%r13, %%r13\n\t"
+      "xorq %%r14, %%r14\n\t"
+      MSM_MONT_ROW(0, r8, r9, r10, r11, r12, r13, r14)
+      MSM_MONT_ROW(1, r9, r10, r11, r12, r13, r14, r8)
+      MSM_MONT_ROW(2, r10, r11, r12, r13, r14, r8, r9)
+      MSM_MONT_ROW(3, r11, r12, r13, r14, r8, r9, r10)
+      MSM_MONT_ROW(4, r12, r13, r14, r8, r9, r10, r11)
+      MSM_MONT_ROW(5, r13, r14, r8, r9, r10, r11, r12)
+      "movq %%r14, 0(%[out])\n\t movq %%r8, 8(%[out])\n\t movq %%r9, 16(%[out])\n\t movq %%r10, 24(%[out])\n\t movq %%r11, 32(%[out])\n\t"
+      "movq %%r12, 40(%[out])\n\t"
+      :
+      : [out] "r"(out), [a] "r"(a), [b] "r"(b), [p] "r"(p), [inv] "m"(inv), [zero] "m"(zero)
+      : "rax", "rbx", "rdx", "r8", "r9", "r10", "r11", "r12", "r13", "r14", "cc", "memory");
+}
+#undef MSM_MONT_ROW
+inline bool cpu_has_mulx_adx() { return __builtin_cpu_supports("bmi2") && __builtin_cpu_supports("adx"); }
+#else
+inline void mont_mul_adx(uint64_t*, const uint64_t*, const uint64_t*, const uint64_t*, uint64_t) {}
+inline bool cpu_has_mulx_adx() { return false; }
+#endif
+
 struct Fp64 {
   using El = F64;
   static constexpr int COORD_BYTES = 48;
   uint64_t p[6];
   uint64_t inv;      // -p^-1 mod 2^64
+  bool adx = false;  // mulx / adcx / adox present: mul() takes the assembly path
   F64 one;           // R mod p
   F64 from28;        // 2^376 mod p: mont_mul(v, from28) turns v = x * 2^392 (device radix) into x * 2^384
   F64 two_d;         // twisted-Edwards 2d (BLS12-377 only), Montgomery form
@@ -84,32 +133,39 @@ struct Fp64 {
   bool is_zero(const F64& a) const { return (a.l[0] | a.l[1] | a.l[2] | a.l[3] | a.l[4] | a.l[5]) == 0; }
   bool eq(const F64& a, const F64& b) const { return memcmp(a.l, b.l, sizeof a.l) == 0; }
 
-  // CIOS Montgomery multiplication (the algorithm of ARK ff montgomery_backend.rs:146-201), r = a b R^-1 mod p, canonical.
+  // Montgomery multiplication, r = a b R^-1 mod p, canonical: CIOS with the two passes of a row fused into one loop and no
+  // carry word above the sixth limb -- the "no-carry" form arkworks uses when the modulus leaves its top bit free
+  // (ARK ff montgomery_backend.rs:146-201, CAN_USE_NO_CARRY_MUL_OPT), which both base fields do (377 and 381 bits of 384).
+  // Two independent 64-bit carry chains per row (A: a_j b_i, C: m p_j); 28 -> 19 ns on the GPU node's EPYC, and the fold of
+  // a small MSM is ~2500 of these.
   void mul(F64& r, const F64& a, const F64& b) const {
-    uint64_t t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int i = 0; i < 6; i++) {
-      unsigned __int128 c = 0;
-      for (int j = 0; j < 6; j++) {
-        c += (unsigned __int128)a.l[j] * b.l[i] + t[j];
-        t[j] = (uint64_t)c;
-        c >>= 64;
-      }
-      c += t[6];
-      t[6] = (uint64_t)c;
-      t[7] = (uint64_t)(c >> 64);
-      const uint64_t m = t[0] * inv;
-      c = (unsigned __int128)m * p[0] + t[0];
-      c >>= 64;
-      for (int j = 1; j < 6; j++) {
-        c += (unsigned __int128)m * p[j] + t[j];
-        t[j - 1] = (uint64_t)c;
-        c >>= 64;
-      }
-      c += t[6];
-      t[5] = (uint64_t)c;
-      t[6] = t[7] + (uint64_t)(c >> 64);
+    if (adx) {
+      uint64_t t[6];
+      mont_mul_adx(t, a.l, b.l, p, inv);
+      cond_sub(t, 0);
+      memcpy(r.l, t, 48);
+      return;
     }
-    cond_sub(t, t[6]);
+    mul_portable(r, a, b);
+  }
+  void mul_portable(F64& r, const F64& a, const F64& b) const {
+    uint64_t t[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < 6; i++) {
+      unsigned __int128 A = (unsigned __int128)a.l[0] * b.l[i] + t[0];
+      const uint64_t m = (uint64_t)A * inv;
+      unsigned __int128 C = (unsigned __int128)m * p[0] + (uint64_t)A;
+      A >>= 64;
+      C >>= 64;
+      for (int j = 1; j < 6; j++) {
+        A += (unsigned __int128)a.l[j] * b.l[i] + t[j];
+        C += (unsigned __int128)m * p[j] + (uint64_t)A;
+        t[j - 1] = (uint64_t)C;
+        A >>= 64;
+        C >>= 64;
+      }
+      t[5] = (uint64_t)C + (uint64_t)A;   // no overflow: p < 2^383
+    }
+    cond_sub(t, 0);
     memcpy(r.l, t, 48);
   }
   void sqr(F64& r, const F64& a) const { mul(r, a, a); }
@@ -158,6 +214,7 @@ struct Fp64 {
     uint64_t x = 1;   // Newton: x <- x (2 - p0 x) doubles the correct low bits
     for (int i = 0; i < 7; i++) x *= 2 - p[0] * x;
     inv = 0 - x;
+    adx = cpu_has_mulx_adx();
     // 2^k mod p by repeated doubling of 1
     F64 v{};
     v.l[0] = 1;

@@ -339,6 +339,7 @@ static int t_f64_op(int op, const uint8_t* a, const uint8_t* b, uint8_t* out) {
     case 1: f.add(z, x, y); break;
     case 2: f.sub(z, x, y); break;
     case 3: f.invert(z, x); break;
+    case 4: f.mul_portable(z, x, y); break;   // the C loop that runs where mulx / adcx / adox are missing
     default: return 1;
   }
   memcpy(out, z.l, 48);

@@ -215,7 +215,8 @@ struct mi355_msm_ctx {
     p.entries = (uint64_t)p.windows * n;
     // entries per accumulate lane: 2^20 lanes at full size; below that fewer, longer lanes win until the chip would go idle
     // (tools/small_k_sweep.py: 24 instead of 8 at 2^17..2^19 pairs: -4..-11 % wall; 36..64 instead of 18..36 at 2^20..2^21: -3 %)
-    const uint64_t k_auto = std::max<uint64_t>({p.entries >= (3u << 20) ? 24u : 8u, p.entries >> 20, std::min<uint64_t>(64, p.entries >> 19)});
+    // (and 4 below 2^18 entries -- a few thousand pairs -- where even 8 additions in a row are a visible share: -4 %)
+    const uint64_t k_auto = std::max<uint64_t>({p.entries >= (3u << 20) ? 24u : (p.entries < (1u << 18) ? 4u : 8u), p.entries >> 20, std::min<uint64_t>(64, p.entries >> 19)});
     uint32_t K = opt_lane_entries ? (uint32_t)opt_lane_entries : (uint32_t)std::min<uint64_t>(256, k_auto);
     p.K = (K + 3) & ~3u;
     p.nlanes = ceil_div(p.entries, p.K);

@@ -341,12 +341,14 @@ __global__ void __launch_bounds__(PART_THREADS) k_l1_scatter(const uint32_t* __r
   // the run offsets of the next window are fetched a whole window step ahead (a global load in the step's critical path
   // would cost ~1.5 us of the ~10 us a step takes)
   // windows below this block's range only advance the digit state (their carry feeds ours)
-  for (uint32_t w = 0; w < w_lo; w++) {
 #pragma unroll
-    for (int k = 0; k < PART_PER_THREAD; k++) {
-      uint32_t mag;
-      bool neg;
-      next_digit(st[k], p.c, p.half, wmask, mag, neg);
+  for (int k = 0; k < PART_PER_THREAD; k++) {
+    if ((uint32_t)k < kmax) {   // (block-uniform; slot by slot, so that empty slots cost nothing)
+      for (uint32_t w = 0; w < w_lo; w++) {
+        uint32_t mag;
+        bool neg;
+        next_digit(st[k], p.c, p.half, wmask, mag, neg);
+      }
     }
   }
   uint32_t offs_next = threadIdx.x < p.b1 ? row[p.shared ? threadIdx.x * p.windows + w_lo : w_lo * p.b1 + threadIdx.x] : 0;
