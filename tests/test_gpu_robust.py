@@ -150,3 +150,38 @@ def test_large_forced_windows_on_small_inputs(ea, oracle, precompute):
         assert ctx.run(sc)[0] == exp, (wb, precompute)
         assert ctx.last_timings()["window_bits"] == wb
         ctx.close()
+
+
+def test_quad_and_single_lane_additions_agree(ea, oracle):
+    """Twisted-Edwards contexts run the fragment merge and the scan reduction with FOUR LANES PER ADDITION below "quad_limit"
+    additions per launch (te.hpp te_add_quad) and one lane per addition above it.  Both forms, and a limit that splits the levels
+    of one MSM between them, give the oracle's bytes -- with skewed scalars (one long run), empty buckets and a ragged size."""
+    import ctypes
+
+    curve, cid = "bls12_377_g1", 0
+    stride = ea.affine_stride(curve)
+    try:
+        for n, wb, fan in ((1, 0, 0), (97, 0, 0), (1000, 7, 4), (4099, 0, 5), (30000, 11, 0), (70001, 0, 8)):
+            bases = ea.generate_points(n, distinct=max(1, n // 5), seed=n + 1, curve=curve)
+            sc = _scalars(n, 3 * n + wb)
+            sc[:, 31] &= 0x0F
+            if n > 10:
+                sc[: n // 3] = sc[0]       # a third of the scalars equal: long runs in every window
+                sc[n // 2, 1:] = 0         # a small scalar: upper windows stay empty
+            exp = ctypes.create_string_buffer(ea.projective_bytes(curve))
+            assert oracle.oracle_msm(cid, bases.ctypes.data, stride, sc.ctypes.data, n, exp, 0) == 0
+            ctx = ea.MultiScalarMultContext(curve)
+            if wb:
+                ctx.set_option("window_bits", wb)
+            if fan:
+                ctx.set_option("seg_entries", fan)
+            ctx.set_bases(bases)
+            for limit in (0, 1 << 18, 300, 1 << 24):
+                ctx.set_option("quad_limit", limit)
+                assert ctx.run(sc)[0] == exp.raw, (n, wb, fan, limit)
+                assert ctx.query("twisted_edwards") == 1
+            ctx.close()
+    finally:
+        c = ea.MultiScalarMultContext(curve)
+        c.set_option("quad_limit", 1 << 18)     # process-wide: restore the default
+        c.close()

@@ -16,7 +16,7 @@ from conftest import ROOT
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
 
-def _compile_kernel(instantiation):
+def _compile_kernel(instantiation, mangled="_ZN3msm17k_accumulate_glds"):
     src = '#include "%s/2022-entries_amd/csrc/msm_kernels.hpp"\nnamespace msm {\n%s\n}\n' % (ROOT, instantiation)
     with tempfile.TemporaryDirectory() as d:
         open(os.path.join(d, "acc.hip"), "w").write(src)
@@ -25,10 +25,10 @@ def _compile_kernel(instantiation):
         assert r.returncode == 0, r.stderr[-2000:]
         asm = open(os.path.join(d, "acc-hip-amdgcn-amd-amdhsa-gfx950.s")).read()
         remarks = r.stderr
-    body = asm[asm.index("_ZN3msm17k_accumulate_glds"):]
+    body = asm[asm.index(mangled):]
     body = body[:body.index("s_endpgm")]
     ops = re.findall(r"^\s+([a-z_0-9]+)", body, flags=re.M)
-    blk = remarks[remarks.index("k_accumulate_glds"):]
+    blk = remarks[remarks.index(mangled.split("msm")[-1].lstrip("0123456789")):]
     res = {k: int(re.search(pat, blk).group(1)) for k, pat in
            (("scratch", r"ScratchSize \[bytes/lane\]: (\d+)"), ("occupancy", r"Occupancy \[waves/SIMD\]: (\d+)"),
             ("vgprs", r"VGPRs: (\d+)"), ("lds", r"LDS Size \[bytes/block\]: (\d+)"))}
@@ -76,6 +76,20 @@ def test_accumulate_kernel_isa(law):
     # against 4.2 for v_cndmask_b32_e64 (profiles/r02_ubench_valu_w4.txt).  In this kernel the difference did not show
     # (profiles/r02_ab_cndmask.txt); the form is pinned anyway so that a scheduling change cannot bring the slow case back
     assert ops.count("v_cndmask_b32_e32") <= 2, ops.count("v_cndmask_b32_e32")
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
+def test_quad_addition_kernel_isa():
+    """The latency form of the scan step: four lanes per addition (te.hpp te_add_quad).  Three multiplications per lane (the
+    one-lane unified addition has nine), operands exchanged by DPP quad permutes, small enough for 4 waves/SIMD, no scratch."""
+    inst = ("template __global__ void k_reduce_scan_step_quad<Bls12_377_Fq>(const XyzzDev*, const XyzzDev*, XyzzDev*, uint32_t, uint32_t, "
+            "uint32_t, uint32_t, uint32_t*);")
+    body, ops, res = _compile_kernel(inst, "_ZN3msm23k_reduce_scan_step_quad")
+    mads = ops.count("v_mad_u64_u32")
+    assert 3 * 378 <= mads <= 3 * 378 + 30, mads
+    assert res["scratch"] == 0 and res["vgprs"] <= 128, res
+    assert body.count("quad_perm") >= 6 * 14       # X<->Y swap of both operands, A / B / Z1Z2 / C to every lane
+    assert "ds_bpermute" not in body and "ds_swizzle" not in body
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
