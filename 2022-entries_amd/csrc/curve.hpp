@@ -475,4 +475,97 @@ MSM_HD void xyzz_add(XyzzT<typename E::T>& acc, const XyzzT<typename E::T>& b, c
   E::template mul_c<false>(acc.zzz, t, ppp, md);
 }
 
+#if defined(__HIPCC__)
+// ---- one full addition by the four lanes of a quad (Fp coordinates) -------------------------------------------------------
+// The latency form of xyzz_add for the kernels that are chains of DEPENDENT additions on an idle chip (fragment merge and
+// scan reduction of small and medium inputs; msm_kernels.hpp).  Lane q of a quad owns coordinate q of both operands and of the
+// result -- 0 X, 1 Y, 2 ZZ, 3 ZZZ, the order they lie in memory -- and the 12M + 2S of add-2008-s become four multiplications
+// in a row, operands exchanged by DPP quad permutes:
+//   1   U1 = X1 ZZ2 | S1 = Y1 ZZZ2 | U2 = X2 ZZ1 | S2 = Y2 ZZZ1          (own a times the b of lane q ^ 2)
+//   2   PP = P^2    | RR = R^2     | ZZ1 ZZ2     | ZZZ1 ZZZ2             (P = U2 - U1, R = S2 - S1)
+//   3   PPP = P PP  | Q = U1 PP    | ZZ3 = (ZZ1 ZZ2) PP | --
+//   4   S1 PPP      | R (Q - X3)   | --          | ZZZ3 = (ZZZ1 ZZZ2) PPP;   X3 = RR - PPP - 2Q,  Y3 = R (Q - X3) - S1 PPP
+// Same bounds as xyzz_add / add_tail.  Infinity operands and the same-x cases (doubling, cancellation) are decided
+// quad-uniformly; the doubling -- rare -- gathers the point and runs the one-lane formula on every lane.
+template <int CTRL>
+__device__ __forceinline__ void fe_quad_perm(Fe& r, const Fe& a) {
+#pragma unroll
+  for (int i = 0; i < NL; i++) r.v[i] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a.v[i], CTRL, 0xf, 0xf, true);
+}
+template <int CTRL>
+__device__ __forceinline__ bool quad_flag(bool z) {   // one lane's flag to the whole quad (CTRL = 0x00 / 0x55 / 0xAA / 0xFF: lane 0..3)
+  return __builtin_amdgcn_update_dpp(0, (int)z, CTRL, 0xf, 0xf, true) != 0;
+}
+__device__ __forceinline__ void fe_select(Fe& r, const Fe& a, const Fe& b, bool take_b) {   // r = take_b ? b : a
+  const LaneMask m = lane_mask(take_b);
+  r = a;
+  fe_cmov(r, b, m);
+}
+
+template <class F>
+__device__ __forceinline__ void xyzz_add_quad(Fe& a, const Fe& b, uint32_t q, const Modulus<F>& md) {
+  using E = FpEl<F>;
+  // infinity <=> ZZ == 0: lane 2 knows
+  if (quad_flag<0xAA>(fe_is_zero_M<F>(b))) return;
+  if (quad_flag<0xAA>(fe_is_zero_M<F>(a))) {
+    a = b;
+    return;
+  }
+  Fe pb, r1, d1, r2, r3, r4, u, v;
+  fe_quad_perm<0x4E>(pb, b);                       // lanes 0 <-> 2, 1 <-> 3
+  fe_mul<F>(r1, a, pb, md);                        // U1 | S1 | U2 | S2
+  fe_quad_perm<0x4E>(d1, r1);
+  fe_sub(d1, d1, r1, F::BIAS2_28);                 // lane 0: P, lane 1: R  -- (0, 4p), limbs < 3*2^28
+  fe_carry(d1);                                    // limbs < 2^28 + 16
+  fe_select(u, a, d1, q < 2);
+  fe_select(v, b, d1, q < 2);
+  fe_mul<F>(r2, u, v, md);                         // PP | RR | ZZ1 ZZ2 | ZZZ1 ZZZ2
+  if (quad_flag<0x00>(fe_is_zero_M<F>(r2))) {
+    // same x: the double of the point, or infinity
+    if (quad_flag<0x55>(fe_is_zero_M<F>(r2))) {
+      Xyzz pt;
+      fe_quad_perm<0x00>(pt.x, a);
+      fe_quad_perm<0x55>(pt.y, a);
+      fe_quad_perm<0xAA>(pt.zz, a);
+      fe_quad_perm<0xFF>(pt.zzz, a);
+      xyzz_dbl<E>(pt, md);
+      fe_select(u, pt.x, pt.y, q == 1);
+      fe_select(v, pt.zz, pt.zzz, q == 3);
+      fe_select(a, u, v, q >= 2);
+    } else {
+      fe_zero(a);
+    }
+    return;
+  }
+  Fe PPb, U1b;
+  fe_quad_perm<0x00>(PPb, r2);
+  fe_quad_perm<0x00>(U1b, r1);
+  fe_select(u, r2, d1, q == 0);
+  fe_select(u, u, U1b, q == 1);
+  fe_mul<F>(r3, u, PPb, md);                       // PPP | Q | ZZ3 | (unused)
+  Fe PPPb, Qb, RRb, S1b, t, x3, d;
+  fe_quad_perm<0x00>(PPPb, r3);
+  fe_quad_perm<0x55>(Qb, r3);
+  fe_quad_perm<0x55>(RRb, r2);
+  fe_quad_perm<0x55>(S1b, r1);
+  fe_dbl(t, Qb);                                   // < 4p, limbs < 2^29
+  fe_add(t, t, PPPb);                              // < 6p, limbs < 3*2^28
+  fe_sub(x3, RRb, t, F::BIAS8_30);                 // (2p, 10p), limbs < 2^28 + 2^30 + 2^28
+  fe_carry(x3);                                    // limbs < 2^28 + 16
+  fe_sub(d, Qb, x3, F::BIAS16_29);                 // (6p, 18p), limbs < 2^30
+  fe_carry(d);
+  fe_select(u, r2, S1b, q == 0);                   // lane 0: S1 PPP;  lane 1: R d;  lane 3: (ZZZ1 ZZZ2) PPP
+  fe_select(u, u, d1, q == 1);
+  fe_select(v, PPPb, d, q == 1);
+  fe_mul<F>(r4, u, v, md);
+  Fe sp, y3;
+  fe_quad_perm<0x00>(sp, r4);                      // S1 PPP
+  fe_sub(y3, r4, sp, F::BIAS2_28);                 // lane 1: R d - S1 PPP, (0, 4p)
+  fe_carry(y3);
+  fe_select(u, x3, y3, q == 1);
+  fe_select(v, r3, r4, q == 3);
+  fe_select(a, u, v, q >= 2);
+}
+#endif
+
 }  // namespace msm

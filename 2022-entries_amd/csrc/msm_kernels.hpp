@@ -405,31 +405,50 @@ __global__ void __launch_bounds__(256, G::ACC_WAVES) k_reduce_scan_step(const Xy
 }
 
 // ------------------------------------------------------------------------------------------------
-// The two latency-bound kernels again, FOUR LANES PER ADDITION (te.hpp te_add_quad; twisted-Edwards contexts only): a step of
+// The two latency-bound kernels again, FOUR LANES PER ADDITION (te.hpp te_add_quad, curve.hpp xyzz_add_quad; G1 only): a step of
 // the scan reduction or a level of the fragment merge on a small input is one dependent addition per wave (~14 us for a lone
 // wave at one instruction per ~5.5 cycles) on a chip that is otherwise idle; with the nine multiplications spread over a quad
-// it is three multiplications deep.  Lane q of a quad owns coordinate q (X, Y, Z, T: the order of XyzzT in memory) of the
+// it is three (Edwards) or four (XYZZ) multiplications deep.  Lane q of a quad owns coordinate q (the order of XyzzT in memory) of the
 // operands and of the result.  Same semantics as k_reduce_scan_step / k_segreduce, which stay in charge above
 // LaunchTe::quad_limit additions per launch, where throughput counts (the quad form spends 4/3 of the instructions).
 // (The first chunked level of the bucket reduction -- 53 K chunks of 128 buckets at 2^26 pairs -- looks latency-bound too but
 // is not: a quad per chunk made it 3.0 -> 3.9 ms.)
-__device__ __forceinline__ bool quad_bcast_z(bool z) {   // lane 2's flag (the Z coordinate) to the whole quad
-  return __builtin_amdgcn_update_dpp(0, (int)z, 0xAA, 0xf, 0xf, true) != 0;
-}
 __device__ __forceinline__ const Fe& xyzz_coord(const XyzzDev* pts, size_t i, uint32_t q) { return reinterpret_cast<const Fe*>(pts + i)[q]; }
 __device__ __forceinline__ Fe& xyzz_coord(XyzzDev* pts, size_t i, uint32_t q) { return reinterpret_cast<Fe*>(pts + i)[q]; }
 
+// What the quad kernels need of a group law: the identity's coordinate q, "this slot was never written" (quad-uniform), and
+// a += b on coordinates (returns true when the law reports a result it could not compute).
 template <class F>
-__device__ __forceinline__ void te_identity_coord(Fe& r, uint32_t q) {   // (0, 1, 1, 0)
-  Fe one, zero;
-  fe_set(one, F::ONE);
-  fe_zero(zero);
-  fe_select(r, zero, one, q == 1 || q == 2);
-}
+struct TeQuad {   // extended twisted Edwards (te.hpp te_add_quad): identity (0, 1, 1, 0); Z = 0 marks an empty bucket / a failure
+  using Fld = F;
+  static __device__ __forceinline__ void identity(Fe& r, uint32_t q) {
+    Fe one, zero;
+    fe_set(one, F::ONE);
+    fe_zero(zero);
+    fe_select(r, zero, one, q == 1 || q == 2);
+  }
+  static __device__ __forceinline__ bool is_empty(const Fe& r) { return quad_flag<0xAA>(fe_is_zero_M<F>(r)); }
+  static __device__ __forceinline__ bool add(Fe& a, const Fe& b, uint32_t q, const Modulus<F>& md) {
+    if (is_empty(b)) return false;
+    te_add_quad<F>(a, b, q, md);
+    return q == 2 && fe_is_zero_M<F>(a);
+  }
+};
+template <class F>
+struct SwQuad {   // XYZZ over Fp (curve.hpp xyzz_add_quad): the all-zero point IS the identity, the law has no failures
+  using Fld = F;
+  static __device__ __forceinline__ void identity(Fe& r, uint32_t) { fe_zero(r); }
+  static __device__ __forceinline__ bool is_empty(const Fe&) { return false; }
+  static __device__ __forceinline__ bool add(Fe& a, const Fe& b, uint32_t q, const Modulus<F>& md) {
+    xyzz_add_quad<F>(a, b, q, md);
+    return false;
+  }
+};
 
-template <class F>
+template <class Q>
 __global__ void __launch_bounds__(256) k_reduce_scan_step_quad(const XyzzDev* __restrict__ in, const XyzzDev* __restrict__ in2, XyzzDev* __restrict__ out,
                                                                uint32_t nb, uint32_t windows, uint32_t d, uint32_t mode, uint32_t* __restrict__ flags) {
+  using F = typename Q::Fld;
   const uint32_t span = mode == 1 ? d : nb;
   const uint32_t gq = blockIdx.x * 256 + threadIdx.x, g = gq >> 2, q = gq & 3;
   if (g >= windows * span) return;
@@ -437,19 +456,15 @@ __global__ void __launch_bounds__(256) k_reduce_scan_step_quad(const XyzzDev* __
   const uint32_t w = g / span, j = g % span;
   const size_t row = (size_t)w * nb;
   Fe r = xyzz_coord(in, row + j, q);
-  if (quad_bcast_z(fe_is_zero_M<F>(r)) || (mode == 2 && j == 0)) te_identity_coord<F>(r, q);   // (a bucket nobody wrote is all zero)
+  if (Q::is_empty(r) || (mode == 2 && j == 0)) Q::identity(r, q);   // (a bucket nobody wrote is all zero)
   const bool have = mode == 2 || j + d < nb;
   if (have) {
     const Fe v = mode == 2 ? xyzz_coord(in2, row + j, q) : xyzz_coord(in, row + j + d, q);
-    if (!quad_bcast_z(fe_is_zero_M<F>(v))) {
-      te_add_quad<F>(r, v, q, md);
-      if (q == 2 && fe_is_zero_M<F>(r)) flags[1] = 1;
-    }
+    if (Q::add(r, v, q, md)) flags[1] = 1;
   }
   xyzz_coord(out, row + j, q) = r;
 }
 
-template <class F>
 __device__ __forceinline__ void seg_flush_quad(const SegOut& o, uint32_t t, uint32_t nlanes, uint32_t key, const Fe& acc, uint32_t q, bool is_first,
                                                bool is_last) {
   const bool complete = (!is_first || t == 0) && (!is_last || t == nlanes - 1);
@@ -462,9 +477,10 @@ __device__ __forceinline__ void seg_flush_quad(const SegOut& o, uint32_t t, uint
   }
 }
 
-template <class F>
+template <class Q>
 __global__ void __launch_bounds__(256) k_segreduce_quad(const XyzzDev* __restrict__ in_slots, const uint32_t* __restrict__ in_keys, uint32_t n_in, uint32_t K,
                                                         SegOut out, uint32_t nlanes, uint32_t* __restrict__ flags) {
+  using F = typename Q::Fld;
   const uint32_t gq = blockIdx.x * 256 + threadIdx.x, t = gq >> 2, q = gq & 3;
   if (t >= nlanes) return;
   Modulus<F> md;
@@ -484,17 +500,16 @@ __global__ void __launch_bounds__(256) k_segreduce_quad(const XyzzDev* __restric
     const Fe v = xyzz_coord(in_slots, e, q);
     if (key != cur) {
       if (cur != KEY_NONE) {
-        seg_flush_quad<F>(out, t, nlanes, cur, acc, q, first, false);
+        seg_flush_quad(out, t, nlanes, cur, acc, q, first, false);
         first = false;
       }
       cur = key;
       acc = v;
-    } else if (!quad_bcast_z(fe_is_zero_M<F>(v))) {
-      te_add_quad<F>(acc, v, q, md);
-      bad |= q == 2 && fe_is_zero_M<F>(acc);
+    } else {
+      bad |= Q::add(acc, v, q, md);
     }
   }
-  if (cur != KEY_NONE) seg_flush_quad<F>(out, t, nlanes, cur, acc, q, first, true);
+  if (cur != KEY_NONE) seg_flush_quad(out, t, nlanes, cur, acc, q, first, true);
   if (bad) flags[1] = 1;
 }
 

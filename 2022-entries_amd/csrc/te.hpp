@@ -135,17 +135,6 @@ MSM_HD void te_add(Xyzz& acc, const Xyzz& b, const Modulus<F>& md) {
 // Three multiplications deep instead of nine; operands travel by DPP quad permutes (X <-> Y between lanes 0 and 1 before
 // step 1, A, B, Z1 Z2, C to every lane before step 3).  Same bounds as te_add / te_tail.  Returns the lane's coordinate of
 // a + b; all four lanes of the quad must call it together.
-template <int CTRL>
-__device__ __forceinline__ void fe_quad_perm(Fe& r, const Fe& a) {
-#pragma unroll
-  for (int i = 0; i < NL; i++) r.v[i] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a.v[i], CTRL, 0xf, 0xf, true);
-}
-__device__ __forceinline__ void fe_select(Fe& r, const Fe& a, const Fe& b, bool take_b) {   // r = take_b ? b : a
-  const LaneMask m = lane_mask(take_b);
-  r = a;
-  fe_cmov(r, b, m);
-}
-
 template <class F>
 __device__ __forceinline__ void te_add_quad(Fe& a, const Fe& b, uint32_t q, const Modulus<F>& md) {
   Fe pa, pb, u, v, t0, t1;

@@ -152,13 +152,14 @@ def test_large_forced_windows_on_small_inputs(ea, oracle, precompute):
         ctx.close()
 
 
-def test_quad_and_single_lane_additions_agree(ea, oracle):
-    """Twisted-Edwards contexts run the fragment merge and the scan reduction with FOUR LANES PER ADDITION below "quad_limit"
-    additions per launch (te.hpp te_add_quad) and one lane per addition above it.  Both forms, and a limit that splits the levels
-    of one MSM between them, give the oracle's bytes -- with skewed scalars (one long run), empty buckets and a ragged size."""
+@pytest.mark.parametrize("curve,cid,te", [("bls12_377_g1", 0, 1), ("bls12_377_g1", 0, 0), ("bls12_381_g1", 1, 0)])
+def test_quad_and_single_lane_additions_agree(ea, oracle, curve, cid, te):
+    """G1 contexts run the fragment merge and the scan reduction with FOUR LANES PER ADDITION below "quad_limit" additions per
+    launch (te.hpp te_add_quad, curve.hpp xyzz_add_quad) and one lane per addition above it.  Both forms, and a limit that
+    splits the levels of one MSM between them, give the oracle's bytes -- with skewed scalars (long runs; equal bases under
+    equal scalars: the XYZZ law's doubling case), empty buckets, cancelling pairs and a ragged size."""
     import ctypes
 
-    curve, cid = "bls12_377_g1", 0
     stride = ea.affine_stride(curve)
     try:
         for n, wb, fan in ((1, 0, 0), (97, 0, 0), (1000, 7, 4), (4099, 0, 5), (30000, 11, 0), (70001, 0, 8)):
@@ -175,13 +176,51 @@ def test_quad_and_single_lane_additions_agree(ea, oracle):
                 ctx.set_option("window_bits", wb)
             if fan:
                 ctx.set_option("seg_entries", fan)
+            if cid == 0:
+                ctx.set_option("twisted_edwards", te)
             ctx.set_bases(bases)
             for limit in (0, 1 << 18, 300, 1 << 24):
                 ctx.set_option("quad_limit", limit)
-                assert ctx.run(sc)[0] == exp.raw, (n, wb, fan, limit)
-                assert ctx.query("twisted_edwards") == 1
+                assert ctx.run(sc)[0] == exp.raw, (curve, te, n, wb, fan, limit)
+                assert ctx.query("twisted_edwards") == te
             ctx.close()
     finally:
         c = ea.MultiScalarMultContext(curve)
         c.set_option("quad_limit", 1 << 18)     # process-wide: restore the default
         c.close()
+
+
+@pytest.mark.parametrize("curve,cid", [("bls12_377_g1", 0), ("bls12_381_g1", 1)])
+def test_quad_xyzz_addition_special_cases(ea, oracle, curve, cid):
+    """The XYZZ quad addition decides infinity operands, the doubling and the cancellation quad-uniformly: P and P in one bucket
+    from different lanes (doubling in the merge), P and -P (cancellation to infinity), buckets that stay empty, and window sums
+    that are equal or opposite (the scan / tree steps add them)."""
+    import ctypes
+
+    C = m.BLS12_377_G1 if cid == 0 else m.BLS12_381_G1
+    rng = random.Random(17 + cid)
+    stride = ea.affine_stride(curve)
+    P, Q = C.mul(5, C.generator()), C.mul(7, C.generator())
+    cases = {
+        "same point many times, equal scalars": ([P] * 64, [rng.randrange(1, C.r)] * 64),
+        "pairs that cancel": ([P, C.neg(P)] * 20 + [Q], [12345] * 40 + [3]),
+        "two blocks whose sums are equal": ([P] * 16 + [Q] * 16, [3 << 8] * 16 + [(3 << 8) + 0] * 16),
+        "everything cancels": ([P, C.neg(P)] * 32, [(1 << 200) + 77] * 64),
+    }
+    for name, (pts, ks) in cases.items():
+        n = len(pts)
+        bases = np.frombuffer(C.encode_affine_array(pts), dtype=np.uint8).reshape(n, stride).copy()
+        sc = np.frombuffer(b"".join(k.to_bytes(32, "little") for k in ks), dtype=np.uint8).reshape(n, 32).copy()
+        exp = ctypes.create_string_buffer(ea.projective_bytes(curve))
+        assert oracle.oracle_msm(cid, bases.ctypes.data, stride, sc.ctypes.data, n, exp, 0) == 0
+        for wb, lanes in ((0, 0), (4, 4), (9, 4)):
+            ctx = ea.MultiScalarMultContext(curve)
+            if cid == 0:
+                ctx.set_option("twisted_edwards", 0)
+            if wb:
+                ctx.set_option("window_bits", wb)
+            if lanes:
+                ctx.set_option("lane_entries", lanes)
+            ctx.set_bases(bases)
+            assert ctx.run(sc)[0] == exp.raw, (curve, name, wb, lanes)
+            ctx.close()

@@ -82,7 +82,7 @@ def test_accumulate_kernel_isa(law):
 def test_quad_addition_kernel_isa():
     """The latency form of the scan step: four lanes per addition (te.hpp te_add_quad).  Three multiplications per lane (the
     one-lane unified addition has nine), operands exchanged by DPP quad permutes, small enough for 4 waves/SIMD, no scratch."""
-    inst = ("template __global__ void k_reduce_scan_step_quad<Bls12_377_Fq>(const XyzzDev*, const XyzzDev*, XyzzDev*, uint32_t, uint32_t, "
+    inst = ("template __global__ void k_reduce_scan_step_quad<TeQuad<Bls12_377_Fq>>(const XyzzDev*, const XyzzDev*, XyzzDev*, uint32_t, uint32_t, "
             "uint32_t, uint32_t, uint32_t*);")
     body, ops, res = _compile_kernel(inst, "_ZN3msm23k_reduce_scan_step_quad")
     mads = ops.count("v_mad_u64_u32")
