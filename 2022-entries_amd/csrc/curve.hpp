@@ -476,7 +476,7 @@ MSM_HD void xyzz_add(XyzzT<typename E::T>& acc, const XyzzT<typename E::T>& b, c
 }
 
 #if defined(__HIPCC__)
-// ---- one full addition by the four lanes of a quad (Fp coordinates) -------------------------------------------------------
+// ---- one full addition by the four lanes of a quad -------------------------------------------------------------------------
 // The latency form of xyzz_add for the kernels that are chains of DEPENDENT additions on an idle chip (fragment merge and
 // scan reduction of small and medium inputs; msm_kernels.hpp).  Lane q of a quad owns coordinate q of both operands and of the
 // result -- 0 X, 1 Y, 2 ZZ, 3 ZZZ, the order they lie in memory -- and the 12M + 2S of add-2008-s become four multiplications
@@ -501,29 +501,41 @@ __device__ __forceinline__ void fe_select(Fe& r, const Fe& a, const Fe& b, bool 
   r = a;
   fe_cmov(r, b, m);
 }
+// the same two helpers for Fp2 coordinates
+template <int CTRL>
+__device__ __forceinline__ void fe_quad_perm(Fe2& r, const Fe2& a) {
+  fe_quad_perm<CTRL>(r.c0, a.c0);
+  fe_quad_perm<CTRL>(r.c1, a.c1);
+}
+__device__ __forceinline__ void fe_select(Fe2& r, const Fe2& a, const Fe2& b, bool take_b) {
+  fe_select(r.c0, a.c0, b.c0, take_b);
+  fe_select(r.c1, a.c1, b.c1, take_b);
+}
 
-template <class F>
-__device__ __forceinline__ void xyzz_add_quad(Fe& a, const Fe& b, uint32_t q, const Modulus<F>& md) {
-  using E = FpEl<F>;
+// E = FpEl<F> (G1) or Fp2El<F, NB> (G2): only the coordinate type and its multiplier differ.
+template <class E>
+__device__ __forceinline__ void xyzz_add_quad(typename E::T& a, const typename E::T& b, uint32_t q, const typename E::Md& md) {
+  using T = typename E::T;
+  using F = typename E::Fld;
   // infinity <=> ZZ == 0: lane 2 knows
-  if (quad_flag<0xAA>(fe_is_zero_M<F>(b))) return;
-  if (quad_flag<0xAA>(fe_is_zero_M<F>(a))) {
+  if (quad_flag<0xAA>(E::is_zero_M(b))) return;
+  if (quad_flag<0xAA>(E::is_zero_M(a))) {
     a = b;
     return;
   }
-  Fe pb, r1, d1, r2, r3, r4, u, v;
+  T pb, r1, d1, r2, r3, r4, u, v;
   fe_quad_perm<0x4E>(pb, b);                       // lanes 0 <-> 2, 1 <-> 3
-  fe_mul<F>(r1, a, pb, md);                        // U1 | S1 | U2 | S2
+  E::mul(r1, a, pb, md);                           // U1 | S1 | U2 | S2
   fe_quad_perm<0x4E>(d1, r1);
-  fe_sub(d1, d1, r1, F::BIAS2_28);                 // lane 0: P, lane 1: R  -- (0, 4p), limbs < 3*2^28
-  fe_carry(d1);                                    // limbs < 2^28 + 16
+  E::sub(d1, d1, r1, F::BIAS2_28);                 // lane 0: P, lane 1: R  -- (0, 4p), limbs < 3*2^28
+  E::carry(d1);                                    // limbs < 2^28 + 16
   fe_select(u, a, d1, q < 2);
   fe_select(v, b, d1, q < 2);
-  fe_mul<F>(r2, u, v, md);                         // PP | RR | ZZ1 ZZ2 | ZZZ1 ZZZ2
-  if (quad_flag<0x00>(fe_is_zero_M<F>(r2))) {
+  E::mul(r2, u, v, md);                            // PP | RR | ZZ1 ZZ2 | ZZZ1 ZZZ2
+  if (quad_flag<0x00>(E::is_zero_M(r2))) {
     // same x: the double of the point, or infinity
-    if (quad_flag<0x55>(fe_is_zero_M<F>(r2))) {
-      Xyzz pt;
+    if (quad_flag<0x55>(E::is_zero_M(r2))) {
+      XyzzT<T> pt;
       fe_quad_perm<0x00>(pt.x, a);
       fe_quad_perm<0x55>(pt.y, a);
       fe_quad_perm<0xAA>(pt.zz, a);
@@ -533,35 +545,35 @@ __device__ __forceinline__ void xyzz_add_quad(Fe& a, const Fe& b, uint32_t q, co
       fe_select(v, pt.zz, pt.zzz, q == 3);
       fe_select(a, u, v, q >= 2);
     } else {
-      fe_zero(a);
+      E::zero(a);
     }
     return;
   }
-  Fe PPb, U1b;
+  T PPb, U1b;
   fe_quad_perm<0x00>(PPb, r2);
   fe_quad_perm<0x00>(U1b, r1);
   fe_select(u, r2, d1, q == 0);
   fe_select(u, u, U1b, q == 1);
-  fe_mul<F>(r3, u, PPb, md);                       // PPP | Q | ZZ3 | (unused)
-  Fe PPPb, Qb, RRb, S1b, t, x3, d;
+  E::mul(r3, u, PPb, md);                          // PPP | Q | ZZ3 | (unused)
+  T PPPb, Qb, RRb, S1b, t, x3, d;
   fe_quad_perm<0x00>(PPPb, r3);
   fe_quad_perm<0x55>(Qb, r3);
   fe_quad_perm<0x55>(RRb, r2);
   fe_quad_perm<0x55>(S1b, r1);
-  fe_dbl(t, Qb);                                   // < 4p, limbs < 2^29
-  fe_add(t, t, PPPb);                              // < 6p, limbs < 3*2^28
-  fe_sub(x3, RRb, t, F::BIAS8_30);                 // (2p, 10p), limbs < 2^28 + 2^30 + 2^28
-  fe_carry(x3);                                    // limbs < 2^28 + 16
-  fe_sub(d, Qb, x3, F::BIAS16_29);                 // (6p, 18p), limbs < 2^30
-  fe_carry(d);
+  E::dbl(t, Qb);                                   // < 4p, limbs < 2^29
+  E::add(t, t, PPPb);                              // < 6p, limbs < 3*2^28
+  E::sub(x3, RRb, t, F::BIAS8_30);                 // (2p, 10p), limbs < 2^28 + 2^30 + 2^28
+  E::carry(x3);                                    // limbs < 2^28 + 16
+  E::sub(d, Qb, x3, F::BIAS16_29);                 // (6p, 18p), limbs < 2^30
+  E::carry(d);
   fe_select(u, r2, S1b, q == 0);                   // lane 0: S1 PPP;  lane 1: R d;  lane 3: (ZZZ1 ZZZ2) PPP
   fe_select(u, u, d1, q == 1);
   fe_select(v, PPPb, d, q == 1);
-  fe_mul<F>(r4, u, v, md);
-  Fe sp, y3;
+  E::mul(r4, u, v, md);
+  T sp, y3;
   fe_quad_perm<0x00>(sp, r4);                      // S1 PPP
-  fe_sub(y3, r4, sp, F::BIAS2_28);                 // lane 1: R d - S1 PPP, (0, 4p)
-  fe_carry(y3);
+  E::sub(y3, r4, sp, F::BIAS2_28);                 // lane 1: R d - S1 PPP, (0, 4p)
+  E::carry(y3);
   fe_select(u, x3, y3, q == 1);
   fe_select(v, r3, r4, q == 3);
   fe_select(a, u, v, q >= 2);

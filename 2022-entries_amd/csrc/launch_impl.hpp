@@ -37,12 +37,10 @@ hipError_t Launch<E>::accumulate(const uint2* entries, const uint32_t* n_real, u
 template <class E>
 hipError_t Launch<E>::segreduce(const XyzzDevT<El>* in_slots, const uint32_t* in_keys, uint32_t n_in, uint32_t K, SegOutT<El> out,
                                 uint32_t nlanes, hipStream_t st) {
-  if constexpr (std::is_same_v<El, Fe>) {
-    if (nlanes <= LaunchTe::quad_limit) {   // latency form: four lanes per addition (msm_kernels.hpp)
-      hipLaunchKernelGGL((k_segreduce_quad<SwQuad<typename E::Fld>>), dim3(launch_blocks(4ull * nlanes)), dim3(256), 0, st, in_slots, in_keys, n_in, K, out,
-                         nlanes, (uint32_t*)nullptr);
-      return hipGetLastError();
-    }
+  if (nlanes <= LaunchTe::quad_limit) {   // latency form: four lanes per addition (msm_kernels.hpp)
+    hipLaunchKernelGGL((k_segreduce_quad<SwQuad<E>>), dim3(launch_blocks(4ull * nlanes)), dim3(256), 0, st, in_slots, in_keys, n_in, K, out, nlanes,
+                       (uint32_t*)nullptr);
+    return hipGetLastError();
   }
   hipLaunchKernelGGL((k_segreduce<SwLaw<E>>), dim3(launch_blocks(nlanes)), dim3(256), 0, st, in_slots, in_keys, n_in, K, out, nlanes, (uint32_t*)nullptr);
   return hipGetLastError();
@@ -65,12 +63,10 @@ template <class E>
 hipError_t Launch<E>::reduce_scan_step(const XyzzDevT<El>* in, const XyzzDevT<El>* in2, XyzzDevT<El>* out, uint32_t nb, uint32_t windows, uint32_t d, uint32_t mode,
                                        hipStream_t st) {
   const uint64_t threads = (uint64_t)windows * (mode == 1 ? d : nb);
-  if constexpr (std::is_same_v<El, Fe>) {
-    if (threads <= LaunchTe::quad_limit) {
-      hipLaunchKernelGGL((k_reduce_scan_step_quad<SwQuad<typename E::Fld>>), dim3(launch_blocks(4 * threads)), dim3(256), 0, st, in, in2, out, nb, windows, d,
-                         mode, (uint32_t*)nullptr);
-      return hipGetLastError();
-    }
+  if (threads <= LaunchTe::quad_limit) {
+    hipLaunchKernelGGL((k_reduce_scan_step_quad<SwQuad<E>>), dim3(launch_blocks(4 * threads)), dim3(256), 0, st, in, in2, out, nb, windows, d, mode,
+                       (uint32_t*)nullptr);
+    return hipGetLastError();
   }
   hipLaunchKernelGGL((k_reduce_scan_step<SwLaw<E>>), dim3(launch_blocks(threads)), dim3(256), 0, st, in, in2, out, nb, windows, d, mode, (uint32_t*)nullptr);
   return hipGetLastError();

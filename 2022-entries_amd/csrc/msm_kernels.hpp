@@ -405,7 +405,7 @@ __global__ void __launch_bounds__(256, G::ACC_WAVES) k_reduce_scan_step(const Xy
 }
 
 // ------------------------------------------------------------------------------------------------
-// The two latency-bound kernels again, FOUR LANES PER ADDITION (te.hpp te_add_quad, curve.hpp xyzz_add_quad; G1 only): a step of
+// The two latency-bound kernels again, FOUR LANES PER ADDITION (te.hpp te_add_quad, curve.hpp xyzz_add_quad): a step of
 // the scan reduction or a level of the fragment merge on a small input is one dependent addition per wave (~14 us for a lone
 // wave at one instruction per ~5.5 cycles) on a chip that is otherwise idle; with the nine multiplications spread over a quad
 // it is three (Edwards) or four (XYZZ) multiplications deep.  Lane q of a quad owns coordinate q (the order of XyzzT in memory) of the
@@ -413,14 +413,17 @@ __global__ void __launch_bounds__(256, G::ACC_WAVES) k_reduce_scan_step(const Xy
 // LaunchTe::quad_limit additions per launch, where throughput counts (the quad form spends 4/3 of the instructions).
 // (The first chunked level of the bucket reduction -- 53 K chunks of 128 buckets at 2^26 pairs -- looks latency-bound too but
 // is not: a quad per chunk made it 3.0 -> 3.9 ms.)
-__device__ __forceinline__ const Fe& xyzz_coord(const XyzzDev* pts, size_t i, uint32_t q) { return reinterpret_cast<const Fe*>(pts + i)[q]; }
-__device__ __forceinline__ Fe& xyzz_coord(XyzzDev* pts, size_t i, uint32_t q) { return reinterpret_cast<Fe*>(pts + i)[q]; }
+template <class T>
+__device__ __forceinline__ const T& xyzz_coord(const XyzzDevT<T>* pts, size_t i, uint32_t q) { return reinterpret_cast<const T*>(pts + i)[q]; }
+template <class T>
+__device__ __forceinline__ T& xyzz_coord(XyzzDevT<T>* pts, size_t i, uint32_t q) { return reinterpret_cast<T*>(pts + i)[q]; }
 
 // What the quad kernels need of a group law: the identity's coordinate q, "this slot was never written" (quad-uniform), and
 // a += b on coordinates (returns true when the law reports a result it could not compute).
 template <class F>
 struct TeQuad {   // extended twisted Edwards (te.hpp te_add_quad): identity (0, 1, 1, 0); Z = 0 marks an empty bucket / a failure
-  using Fld = F;
+  using T = Fe;
+  using Md = Modulus<F>;
   static __device__ __forceinline__ void identity(Fe& r, uint32_t q) {
     Fe one, zero;
     fe_set(one, F::ONE);
@@ -434,38 +437,41 @@ struct TeQuad {   // extended twisted Edwards (te.hpp te_add_quad): identity (0,
     return q == 2 && fe_is_zero_M<F>(a);
   }
 };
-template <class F>
-struct SwQuad {   // XYZZ over Fp (curve.hpp xyzz_add_quad): the all-zero point IS the identity, the law has no failures
-  using Fld = F;
-  static __device__ __forceinline__ void identity(Fe& r, uint32_t) { fe_zero(r); }
-  static __device__ __forceinline__ bool is_empty(const Fe&) { return false; }
-  static __device__ __forceinline__ bool add(Fe& a, const Fe& b, uint32_t q, const Modulus<F>& md) {
-    xyzz_add_quad<F>(a, b, q, md);
+template <class E>
+struct SwQuad {   // XYZZ (curve.hpp xyzz_add_quad), Fp or Fp2 coordinates: the all-zero point IS the identity, the law has no failures
+  using T = typename E::T;
+  using Md = typename E::Md;
+  static __device__ __forceinline__ void identity(T& r, uint32_t) { E::zero(r); }
+  static __device__ __forceinline__ bool is_empty(const T&) { return false; }
+  static __device__ __forceinline__ bool add(T& a, const T& b, uint32_t q, const Md& md) {
+    xyzz_add_quad<E>(a, b, q, md);
     return false;
   }
 };
 
 template <class Q>
-__global__ void __launch_bounds__(256) k_reduce_scan_step_quad(const XyzzDev* __restrict__ in, const XyzzDev* __restrict__ in2, XyzzDev* __restrict__ out,
+__global__ void __launch_bounds__(256) k_reduce_scan_step_quad(const XyzzDevT<typename Q::T>* __restrict__ in, const XyzzDevT<typename Q::T>* __restrict__ in2,
+                                                               XyzzDevT<typename Q::T>* __restrict__ out,
                                                                uint32_t nb, uint32_t windows, uint32_t d, uint32_t mode, uint32_t* __restrict__ flags) {
-  using F = typename Q::Fld;
+  using T = typename Q::T;
   const uint32_t span = mode == 1 ? d : nb;
   const uint32_t gq = blockIdx.x * 256 + threadIdx.x, g = gq >> 2, q = gq & 3;
   if (g >= windows * span) return;
-  Modulus<F> md;
+  typename Q::Md md;
   const uint32_t w = g / span, j = g % span;
   const size_t row = (size_t)w * nb;
-  Fe r = xyzz_coord(in, row + j, q);
+  T r = xyzz_coord(in, row + j, q);
   if (Q::is_empty(r) || (mode == 2 && j == 0)) Q::identity(r, q);   // (a bucket nobody wrote is all zero)
   const bool have = mode == 2 || j + d < nb;
   if (have) {
-    const Fe v = mode == 2 ? xyzz_coord(in2, row + j, q) : xyzz_coord(in, row + j + d, q);
+    const T v = mode == 2 ? xyzz_coord(in2, row + j, q) : xyzz_coord(in, row + j + d, q);
     if (Q::add(r, v, q, md)) flags[1] = 1;
   }
   xyzz_coord(out, row + j, q) = r;
 }
 
-__device__ __forceinline__ void seg_flush_quad(const SegOut& o, uint32_t t, uint32_t nlanes, uint32_t key, const Fe& acc, uint32_t q, bool is_first,
+template <class T>
+__device__ __forceinline__ void seg_flush_quad(const SegOutT<T>& o, uint32_t t, uint32_t nlanes, uint32_t key, const T& acc, uint32_t q, bool is_first,
                                                bool is_last) {
   const bool complete = (!is_first || t == 0) && (!is_last || t == nlanes - 1);
   if (complete) {
@@ -478,12 +484,12 @@ __device__ __forceinline__ void seg_flush_quad(const SegOut& o, uint32_t t, uint
 }
 
 template <class Q>
-__global__ void __launch_bounds__(256) k_segreduce_quad(const XyzzDev* __restrict__ in_slots, const uint32_t* __restrict__ in_keys, uint32_t n_in, uint32_t K,
-                                                        SegOut out, uint32_t nlanes, uint32_t* __restrict__ flags) {
-  using F = typename Q::Fld;
+__global__ void __launch_bounds__(256) k_segreduce_quad(const XyzzDevT<typename Q::T>* __restrict__ in_slots, const uint32_t* __restrict__ in_keys, uint32_t n_in, uint32_t K,
+                                                        SegOutT<typename Q::T> out, uint32_t nlanes, uint32_t* __restrict__ flags) {
+  using T = typename Q::T;
   const uint32_t gq = blockIdx.x * 256 + threadIdx.x, t = gq >> 2, q = gq & 3;
   if (t >= nlanes) return;
-  Modulus<F> md;
+  typename Q::Md md;
   if (q == 0) {
     out.slot_keys[2 * (size_t)t] = KEY_NONE;
     out.slot_keys[2 * (size_t)t + 1] = KEY_NONE;
@@ -492,12 +498,12 @@ __global__ void __launch_bounds__(256) k_segreduce_quad(const XyzzDev* __restric
   const uint64_t end = (beg + K < n_in) ? beg + K : n_in;
   uint32_t cur = KEY_NONE;
   bool first = true, bad = false;
-  Fe acc;
-  fe_zero(acc);
+  T acc;
+  Q::identity(acc, q);
   for (uint64_t e = beg; e < end; e++) {
     const uint32_t key = in_keys[e];
     if (key == KEY_NONE) continue;
-    const Fe v = xyzz_coord(in_slots, e, q);
+    const T v = xyzz_coord(in_slots, e, q);
     if (key != cur) {
       if (cur != KEY_NONE) {
         seg_flush_quad(out, t, nlanes, cur, acc, q, first, false);

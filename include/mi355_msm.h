@@ -118,7 +118,7 @@ RustError mi355_msm_run_device(mi355_msm_ctx* ctx, void* out_projective, const v
  * Tuning knobs ("window_bits" 2..24, "lane_entries", "max_chunk" <= 2^27, "seg_entries" >= 4, "reduce_log_chunk" /
  * "reduce_log_chunk0" 1..7: bucket-reduction chunk sizes on all / the first level); 0 restores the automatic choice.
  * "reduce_scan" = 0 keeps the bucket reduction on the recursive chunked scheme only (default: its tail is a parallel scan).
- * "quad_limit" (process-wide, default 2^18): G1 merge / scan launches of at most that many additions spread each
+ * "quad_limit" (process-wide, default 2^18): merge / scan launches of at most that many additions spread each
  * addition over four lanes (latency); 0 = always one lane per addition.
  * Test hooks: "mem_limit" (bytes of device memory chunks may be planned against), "inject_alloc_failures".
  * "scalars_montgomery" = 1 makes every run treat the scalars as arkworks `Fr` values (Montgomery form, a*2^256 mod r)

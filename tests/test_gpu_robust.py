@@ -152,7 +152,7 @@ def test_large_forced_windows_on_small_inputs(ea, oracle, precompute):
         ctx.close()
 
 
-@pytest.mark.parametrize("curve,cid,te", [("bls12_377_g1", 0, 1), ("bls12_377_g1", 0, 0), ("bls12_381_g1", 1, 0)])
+@pytest.mark.parametrize("curve,cid,te", [("bls12_377_g1", 0, 1), ("bls12_377_g1", 0, 0), ("bls12_381_g1", 1, 0), ("bls12_377_g2", 2, 0)])
 def test_quad_and_single_lane_additions_agree(ea, oracle, curve, cid, te):
     """G1 contexts run the fragment merge and the scan reduction with FOUR LANES PER ADDITION below "quad_limit" additions per
     launch (te.hpp te_add_quad, curve.hpp xyzz_add_quad) and one lane per addition above it.  Both forms, and a limit that
@@ -163,6 +163,8 @@ def test_quad_and_single_lane_additions_agree(ea, oracle, curve, cid, te):
     stride = ea.affine_stride(curve)
     try:
         for n, wb, fan in ((1, 0, 0), (97, 0, 0), (1000, 7, 4), (4099, 0, 5), (30000, 11, 0), (70001, 0, 8)):
+            if cid == 2 and n > 5000:
+                continue
             bases = ea.generate_points(n, distinct=max(1, n // 5), seed=n + 1, curve=curve)
             sc = _scalars(n, 3 * n + wb)
             sc[:, 31] &= 0x0F
