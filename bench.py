@@ -333,6 +333,31 @@ def main():
                 except Exception as e:
                     sec[name] = {"error": repr(e)}
             out["secondary_configs"] = sec
+            # Latency of small inputs (BASELINE.json configs[0] is 2^16): wall ms of one MSM, median of 15,
+            # bases and scalars resident, with the device-side share.
+            lat = {}
+            try:
+                for npow2 in (10, 16, 20):
+                    n2 = 1 << npow2
+                    c2 = ea.MultiScalarMultContext(args.curve, device=local_rank)
+                    c2.set_bases(tile[:n2].contiguous() if n2 <= distinct else tile.repeat(n2 // distinct, 1).contiguous())
+                    sc2 = uniform_scalars(n2, R377_TOP, device, seed=7)
+                    for _ in range(3):
+                        c2.run(sc2)
+                    ts = []
+                    for _ in range(15):
+                        torch.cuda.synchronize()
+                        t1 = time.perf_counter()
+                        c2.run(sc2)
+                        ts.append(time.perf_counter() - t1)
+                    ts.sort()
+                    tm2 = c2.last_timings()
+                    lat["2^%d" % npow2] = {"wall_ms": ts[7] * 1e3, "device_ms": tm2["total"], "host_fold_ms": tm2["host_fold"],
+                                           "window_bits": tm2["window_bits"]}
+                    c2.close()
+            except Exception as e:
+                lat["error"] = repr(e)
+            out["small_input_latency"] = lat
         if world == 1 and not c_sharded and args.cpu_sample_pow > 0:
             sample = min(n, 1 << args.cpu_sample_pow)
             cores = os.cpu_count() or 1
