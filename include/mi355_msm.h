@@ -117,7 +117,8 @@ RustError mi355_msm_run_device(mi355_msm_ctx* ctx, void* out_projective, const v
  * the untimed init and in HBM (windows x 128 B per base: 94 GB at 2^26).  Results are identical.
  * Tuning knobs ("window_bits" 2..24, "lane_entries", "max_chunk" <= 2^27, "seg_entries" >= 4, "reduce_log_chunk" /
  * "reduce_log_chunk0" 1..7: bucket-reduction chunk sizes on all / the first level); 0 restores the automatic choice.
- * "reduce_scan" = 0 keeps the bucket reduction on the recursive chunked scheme only (default: its tail is a parallel scan).
+ * "reduce_scan" = 0 keeps the bucket reduction on the recursive chunked scheme only (default: its tail is a parallel scan);
+ * "reduce_scan_log" 6..18 = log2 of the elements per window at which the scan takes over (default 12).
  * "quad_limit" (process-wide, default 2^18): merge / scan launches of at most that many additions spread each
  * addition over four lanes (latency); 0 = always one lane per addition.
  * Test hooks: "mem_limit" (bytes of device memory chunks may be planned against), "inject_alloc_failures".
