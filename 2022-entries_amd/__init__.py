@@ -18,6 +18,7 @@ from .msm import (  # noqa: F401
     multi_scalar_mult_init,
     plan,
     msm,
+    last_stateless,
 )
 from .dist import all_gather_partials, shard_bounds, sharded_msm  # noqa: F401,E402
 from . import formats  # noqa: F401,E402

@@ -78,7 +78,7 @@ def build_shims(force: bool = False) -> list:
     outs = []
     shim_dir = os.path.join(CSRC, "shims")
     variants = [("sppark_stateless.c", "sppark", ("377", "381")), ("zprize_harness.c", "zprize", ("377", "381")),
-                ("yrrid_context.c", "yrrid", ("377",))]
+                ("yrrid_context.c", "yrrid", ("377",)), ("north_star_msm.c", "msm", ("377", "381"))]
     for src, name, curves in variants:
         for cv in curves:
             out = os.path.join(PKG, f"libmi355msm_{name}_{cv}.so")

@@ -10,8 +10,6 @@ using G = TeLaw<Bls12_377_Fq>;
 inline uint32_t te_blocks(uint64_t n) { return (uint32_t)((n + 255) / 256); }
 }  // namespace
 
-uint32_t LaunchTe::quad_limit = 1u << 18;   // tools/quad_limit_sweep.py: flat from 2^16 up, 2^18 best at 2^20 pairs
-
 hipError_t LaunchTe::convert(const AffineDev* in, const uint8_t* inf, uint32_t n, uint32_t J, Fe* prefix, TeAffineDev* out, uint32_t* flags,
                              hipStream_t st) {
   hipLaunchKernelGGL((k_te_convert<Bls12_377_Fq>), dim3(te_blocks(((uint64_t)n + J - 1) / J)), dim3(256), 0, st, in, inf, n, J, prefix, out, flags);
@@ -25,7 +23,7 @@ hipError_t LaunchTe::accumulate(const uint2* entries, const uint32_t* n_real, ui
 }
 
 hipError_t LaunchTe::segreduce(const XyzzDev* in_slots, const uint32_t* in_keys, uint32_t n_in, uint32_t K, SegOut out, uint32_t nlanes,
-                               uint32_t* flags, hipStream_t st) {
+                               uint32_t quad_limit, uint32_t* flags, hipStream_t st) {
   if (nlanes <= quad_limit)
     hipLaunchKernelGGL((k_segreduce_quad<TeQuad<Bls12_377_Fq>>), dim3(te_blocks(4ull * nlanes)), dim3(256), 0, st, in_slots, in_keys, n_in, K, out, nlanes, flags);
   else
@@ -43,8 +41,8 @@ hipError_t LaunchTe::bucket_reduce(bool first, const XyzzDev* in_a, const XyzzDe
   return hipGetLastError();
 }
 
-hipError_t LaunchTe::reduce_scan_step(const XyzzDev* in, const XyzzDev* in2, XyzzDev* out, uint32_t nb, uint32_t windows, uint32_t d, uint32_t mode, uint32_t* flags,
-                                      hipStream_t st) {
+hipError_t LaunchTe::reduce_scan_step(const XyzzDev* in, const XyzzDev* in2, XyzzDev* out, uint32_t nb, uint32_t windows, uint32_t d, uint32_t mode,
+                                      uint32_t quad_limit, uint32_t* flags, hipStream_t st) {
   const uint64_t threads = (uint64_t)windows * (mode == 1 ? d : nb);
   if (threads <= quad_limit)
     hipLaunchKernelGGL((k_reduce_scan_step_quad<TeQuad<Bls12_377_Fq>>), dim3(te_blocks(4 * threads)), dim3(256), 0, st, in, in2, out, nb, windows, d, mode, flags);

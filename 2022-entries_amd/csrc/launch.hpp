@@ -18,8 +18,10 @@ struct Launch {
                                   hipStream_t st);
   static hipError_t accumulate(const uint2* entries, const uint32_t* n_real, uint32_t K,
                                const AffineDevT<El>* bases, SegOutT<El> out, uint32_t nlanes, hipStream_t st);
+  // `quad_limit` (per context, option "quad_limit"): launches of at most that many additions use the four-lanes-per-addition
+  // kernels (latency), larger ones one lane each (throughput)
   static hipError_t segreduce(const XyzzDevT<El>* in_slots, const uint32_t* in_keys, uint32_t n_in, uint32_t K, SegOutT<El> out,
-                              uint32_t nlanes, hipStream_t st);
+                              uint32_t nlanes, uint32_t quad_limit, hipStream_t st);
   static hipError_t pre_double(const AffineDevT<El>* in, const uint8_t* inf_in, uint32_t n, uint32_t c, XyzzDevT<El>* out, hipStream_t st);
   static hipError_t pre_normalize(const XyzzDevT<El>* in, uint32_t n, uint32_t J, El* prefix, AffineDevT<El>* out, uint8_t* inf_out,
                                   hipStream_t st);
@@ -27,24 +29,23 @@ struct Launch {
                                   uint32_t chunks, uint32_t windows, XyzzDevT<El>* out_a, XyzzDevT<El>* out_x, hipStream_t st);
   // small windows: one step of the scan-based reduction (k_reduce_scan_step)
   static hipError_t reduce_scan_step(const XyzzDevT<El>* in, const XyzzDevT<El>* in2, XyzzDevT<El>* out, uint32_t nb, uint32_t windows, uint32_t d, uint32_t mode,
-                                     hipStream_t st);
+                                     uint32_t quad_limit, hipStream_t st);
 };
 
 // The twisted-Edwards fast path of BLS12-377 G1 (kernels_377te.hip).  `flags`: [0] += bases without an image (convert),
 // [1] = 1 when an addition hit a vanishing denominator (any walking kernel).
 struct LaunchTe {
-  // launches of at most this many additions use the four-lanes-per-addition kernels (latency), larger ones one lane each (throughput)
-  static uint32_t quad_limit;
+  static constexpr uint32_t kDefaultQuadLimit = 1u << 18;   // tools/quad_limit_sweep.py: flat from 2^16 up, 2^18 best at 2^20 pairs
   static hipError_t convert(const AffineDev* in, const uint8_t* inf, uint32_t n, uint32_t J, Fe* prefix, TeAffineDev* out, uint32_t* flags,
                             hipStream_t st);
   static hipError_t accumulate(const uint2* entries, const uint32_t* n_real, uint32_t K,
                                const TeAffineDev* bases, SegOut out, uint32_t nlanes, uint32_t* flags, hipStream_t st);
   static hipError_t segreduce(const XyzzDev* in_slots, const uint32_t* in_keys, uint32_t n_in, uint32_t K, SegOut out, uint32_t nlanes,
-                              uint32_t* flags, hipStream_t st);
+                              uint32_t quad_limit, uint32_t* flags, hipStream_t st);
   static hipError_t bucket_reduce(bool first, const XyzzDev* in_a, const XyzzDev* in_x, uint32_t n_per_win, uint32_t logL, uint32_t chunks,
                                   uint32_t windows, XyzzDev* out_a, XyzzDev* out_x, uint32_t* flags, hipStream_t st);
-  static hipError_t reduce_scan_step(const XyzzDev* in, const XyzzDev* in2, XyzzDev* out, uint32_t nb, uint32_t windows, uint32_t d, uint32_t mode, uint32_t* flags,
-                                     hipStream_t st);
+  static hipError_t reduce_scan_step(const XyzzDev* in, const XyzzDev* in2, XyzzDev* out, uint32_t nb, uint32_t windows, uint32_t d, uint32_t mode,
+                                     uint32_t quad_limit, uint32_t* flags, hipStream_t st);
 };
 
 // Bucket grouping (partition.hip): digits + MSD partition of the (key, value) entries.  scalar_field: 0 = BLS12-377 Fr, 1 = BLS12-381 Fr

@@ -36,8 +36,8 @@ hipError_t Launch<E>::accumulate(const uint2* entries, const uint32_t* n_real, u
 
 template <class E>
 hipError_t Launch<E>::segreduce(const XyzzDevT<El>* in_slots, const uint32_t* in_keys, uint32_t n_in, uint32_t K, SegOutT<El> out,
-                                uint32_t nlanes, hipStream_t st) {
-  if (nlanes <= LaunchTe::quad_limit) {   // latency form: four lanes per addition (msm_kernels.hpp)
+                                uint32_t nlanes, uint32_t quad_limit, hipStream_t st) {
+  if (nlanes <= quad_limit) {   // latency form: four lanes per addition (msm_kernels.hpp)
     hipLaunchKernelGGL((k_segreduce_quad<SwQuad<E>>), dim3(launch_blocks(4ull * nlanes)), dim3(256), 0, st, in_slots, in_keys, n_in, K, out, nlanes,
                        (uint32_t*)nullptr);
     return hipGetLastError();
@@ -61,9 +61,9 @@ hipError_t Launch<E>::bucket_reduce(bool first, const XyzzDevT<El>* in_a, const 
 
 template <class E>
 hipError_t Launch<E>::reduce_scan_step(const XyzzDevT<El>* in, const XyzzDevT<El>* in2, XyzzDevT<El>* out, uint32_t nb, uint32_t windows, uint32_t d, uint32_t mode,
-                                       hipStream_t st) {
+                                       uint32_t quad_limit, hipStream_t st) {
   const uint64_t threads = (uint64_t)windows * (mode == 1 ? d : nb);
-  if (threads <= LaunchTe::quad_limit) {
+  if (threads <= quad_limit) {
     hipLaunchKernelGGL((k_reduce_scan_step_quad<SwQuad<E>>), dim3(launch_blocks(4 * threads)), dim3(256), 0, st, in, in2, out, nb, windows, d, mode,
                        (uint32_t*)nullptr);
     return hipGetLastError();

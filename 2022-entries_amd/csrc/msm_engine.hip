@@ -80,8 +80,29 @@ RustError guarded(Fn&& fn) {
   }
 }
 
-// Test hook ("inject_alloc_failures" option): the next N work-buffer reservations of this thread's chunks fail as if HBM were exhausted.
-thread_local long g_inject_alloc_failures = 0;
+// The calling thread's current HIP device is the CALLER's state (a torch process keeps allocating on it): every entry point
+// that switches devices -- a context bound to another GPU, the shards of a sharded context -- restores it on the way out.
+struct DeviceGuard {
+  int prev = -1;
+  DeviceGuard() {
+    if (hipGetDevice(&prev) != hipSuccess) {
+      prev = -1;
+      (void)hipGetLastError();
+    }
+  }
+  ~DeviceGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+  DeviceGuard(const DeviceGuard&) = delete;
+  DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+
+// `guarded` for the entry points that touch a device: the caller's current device is the same before and after.
+template <class Fn>
+RustError guarded_dev(Fn&& fn) {
+  DeviceGuard keep;
+  return guarded(fn);
+}
 
 struct DevBuf {
   void* p = nullptr;
@@ -162,6 +183,7 @@ struct mi355_msm_ctx {
   hipEvent_t copy_ev[3] = {};   // batch parity 0/1 resident, first piece of batch 0 resident
   size_t nbases = 0;
   DevBuf bases, inf;
+  DevBuf stateless_raw[3];   // raw base records of the stateless pipeline (msm_stateless.hpp), kept with a cached context
   DevBuf scalars, entries[2], buckets, slots[2], slot_keys[2], red_a[2], red_x[2];
   DevBuf part_matrix, part_partial, part_segs[2], part_subjobs, part_counts, part_totals;   // bucket grouping scratch (partition_plan.hpp)
   void* pinned = nullptr;  // window sums land here
@@ -181,10 +203,12 @@ struct mi355_msm_ctx {
   uint32_t te_fallback_streak = 0;   // consecutive chunks that fell back; two in a row demote the context to XYZZ for good
   uint64_t te_demotions = 0;
   uint64_t oom_backoffs = 0;      // chunks restarted with half the chunk size after a device allocation failed
-  size_t chunk_cap = 0;           // 0 = none; otherwise the largest chunk the work buffers were found to fit (see fit_chunk)
+  size_t chunk_cap = 0;           // what the most recent run had to cap its chunks at after an allocation failed (0 = it never had to); reported, not kept
   size_t fitted_chunk = 0;        // largest chunk that has run with the current buffers and options (skips the fit query)
   bool fitted_tables = false;
   long opt_mem_limit = 0;         // test hook: pretend the device has at most this many free bytes when sizing chunks
+  long inject_alloc_failures = 0; // test hook: the next N work-buffer reservations of THIS context fail as if HBM were exhausted
+  uint32_t quad_limit = LaunchTe::kDefaultQuadLimit;   // merge / scan launches of at most this many additions run four lanes per addition
   // sharded context (mi355_msm_create_sharded): this object then owns no device state itself, only the per-device children
   std::vector<mi355_msm_ctx*> shards;
   std::vector<size_t> shard_lo;   // bases [shard_lo[g], shard_lo[g+1]) live on shard g
@@ -267,6 +291,46 @@ DevBuf* const* work_buffers(mi355_msm_ctx* ctx, size_t& count) {
   count = sizeof list / sizeof list[0];
   for (size_t i = 0; i < count; i++) bufs[i] = list[i];
   return bufs;
+}
+
+// Bytes of each per-chunk work buffer, in the order of work_buffers(): what run_chunk reserves for a chunk of n pairs under
+// plan p (`xyzz` = sizeof(XyzzDev) of the curve).  Separate from the reservation so that a caller that knows all its chunk
+// sizes in advance (the stateless pipeline) can take the element-wise maximum and allocate ONCE.
+struct WorkBytes {
+  size_t b[18] = {};
+  void max_with(const WorkBytes& o) {
+    for (int i = 0; i < 18; i++) b[i] = std::max(b[i], o.b[i]);
+  }
+};
+
+WorkBytes chunk_work_bytes(const Plan& p, size_t n, bool use_tables, size_t xyzz) {
+  WorkBytes w;
+  const PartPlan gp = part_plan((uint32_t)n, p.c, p.windows, use_tables, 0, 0);
+  const PartScratchSizes gs = part_scratch_sizes(gp);
+  const size_t nbuckets = (size_t)p.bucket_windows * p.half, nslots0 = 2 * (size_t)p.nlanes;
+  const size_t red0 = p.scan_direct ? nbuckets : (size_t)p.bucket_windows * p.T0;   // direct scan: a second bucket-sized array to ping-pong with
+  w.b[0] = w.b[1] = p.entries * 8 + 64;
+  w.b[2] = gs.matrix;
+  w.b[3] = gs.partial;
+  w.b[4] = gs.segs_a;
+  w.b[5] = gs.segs_b;
+  w.b[6] = gs.subjob_first;
+  w.b[7] = gs.counts;
+  w.b[8] = gs.totals;
+  w.b[9] = nbuckets * xyzz;
+  w.b[10] = w.b[11] = nslots0 * xyzz;
+  w.b[12] = w.b[13] = nslots0 * 4;
+  w.b[14] = red0 * xyzz;                          // red_a[0]
+  w.b[15] = p.scan_direct ? 0 : red0 * xyzz;      // red_a[1]
+  w.b[16] = w.b[17] = p.scan_direct ? 0 : red0 * xyzz;   // red_x[0], red_x[1]
+  return w;
+}
+
+void reserve_work(mi355_msm_ctx* ctx, const WorkBytes& w) {
+  size_t nb = 0;
+  DevBuf* const* wb = work_buffers(ctx, nb);
+  for (size_t i = 0; i < nb; i++)
+    if (w.b[i]) wb[i]->reserve(w.b[i]);
 }
 
 // The largest chunk (<= want) whose work buffers fit the device memory that is free now or already held by this context
@@ -412,6 +476,7 @@ void set_bases_device(mi355_msm_ctx* ctx, const void* d_affine, size_t n, size_t
   if (n >= (1ull << 31)) bad_arg("npoints %zu exceeds 2^31-1", n);
   ctx->pre_c = ctx->pre_windows = 0;
   ctx->nbases = 0;
+  ctx->fitted_chunk = 0;   // the plan (tables, window size) may change with the base set: fit the first chunk again
   ctx->te_active = false;
   ctx->te_fallback_streak = 0;
   ctx->sw_level0_only = false;
@@ -502,34 +567,14 @@ bool run_chunk_impl(mi355_msm_ctx* ctx, const uint32_t* d_scalars, size_t base0,
   const Plan p = ctx->plan(n, use_tables);
   if (p.entries >= (1ull << 32)) bad_arg("chunk of %zu pairs needs %llu sort entries (>= 2^32)", n, (unsigned long long)p.entries);
   const size_t NE = p.entries;
-  if (g_inject_alloc_failures > 0) {
-    g_inject_alloc_failures--;
+  if (ctx->inject_alloc_failures > 0) {
+    ctx->inject_alloc_failures--;
     throw HipFailure((int)hipErrorOutOfMemory, "work-buffer reservation failed: out of memory (injected by the inject_alloc_failures test hook)");
   }
-  for (int i = 0; i < 2; i++) ctx->entries[i].reserve(NE * 8 + 64);
+  reserve_work(ctx, chunk_work_bytes(p, n, use_tables, sizeof(XyzzDev)));
   const uint32_t table_stride = use_tables ? (uint32_t)ctx->nbases : 0u;
   const PartPlan gp = part_plan((uint32_t)n, p.c, p.windows, use_tables, (uint32_t)base0, table_stride);
-  const PartScratchSizes gs = part_scratch_sizes(gp);
-  ctx->part_matrix.reserve(gs.matrix);
-  ctx->part_partial.reserve(gs.partial);
-  ctx->part_segs[0].reserve(gs.segs_a);
-  ctx->part_segs[1].reserve(gs.segs_b);
-  ctx->part_subjobs.reserve(gs.subjob_first);
-  ctx->part_counts.reserve(gs.counts);
-  ctx->part_totals.reserve(gs.totals);
   const size_t nbuckets = (size_t)p.bucket_windows * p.half;
-  ctx->buckets.reserve(nbuckets * sizeof(XyzzDev));
-  const size_t nslots0 = 2 * (size_t)p.nlanes;
-  for (int i = 0; i < 2; i++) {
-    ctx->slots[i].reserve(nslots0 * sizeof(XyzzDev));
-    ctx->slot_keys[i].reserve(nslots0 * 4);
-  }
-  const size_t red0 = p.scan_direct ? nbuckets : (size_t)p.bucket_windows * p.T0;   // direct scan: a second bucket-sized array to ping-pong with
-  for (int i = 0; i < 2; i++) {
-    if (p.scan_direct && i == 1) break;
-    ctx->red_a[i].reserve(red0 * sizeof(XyzzDev));
-    if (!p.scan_direct) ctx->red_x[i].reserve(red0 * sizeof(XyzzDev));
-  }
   if (ctx->pinned_bytes < p.windows * sizeof(XyzzDev)) {
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     ctx->pinned_bytes = 64 * sizeof(XyzzDev) > p.windows * sizeof(XyzzDev) ? 64 * sizeof(XyzzDev) : p.windows * sizeof(XyzzDev);
@@ -577,9 +622,9 @@ bool run_chunk_impl(mi355_msm_ctx* ctx, const uint32_t* d_scalars, size_t base0,
       if (nl > 1 && 2 * (uint64_t)nl >= n_in) bad_arg("fragment merge would not shrink (%u slots, fan-in %u)", n_in, p.segK);
       SegOut o{ctx->buckets.as<XyzzDev>(), ctx->slots[cur ^ 1].as<XyzzDev>(), ctx->slot_keys[cur ^ 1].as<uint32_t>()};
       if constexpr (TE)
-        HIP_OK(LaunchTe::segreduce(ctx->slots[cur].as<XyzzDev>(), ctx->slot_keys[cur].as<uint32_t>(), n_in, p.segK, o, nl, flags, st));
+        HIP_OK(LaunchTe::segreduce(ctx->slots[cur].as<XyzzDev>(), ctx->slot_keys[cur].as<uint32_t>(), n_in, p.segK, o, nl, ctx->quad_limit, flags, st));
       else
-        HIP_OK(Launch<E>::segreduce(ctx->slots[cur].as<XyzzDev>(), ctx->slot_keys[cur].as<uint32_t>(), n_in, p.segK, o, nl, st));
+        HIP_OK(Launch<E>::segreduce(ctx->slots[cur].as<XyzzDev>(), ctx->slot_keys[cur].as<uint32_t>(), n_in, p.segK, o, nl, ctx->quad_limit, st));
       if (nl == 1) break;
       n_in = 2 * nl;
       cur ^= 1;
@@ -611,9 +656,9 @@ bool run_chunk_impl(mi355_msm_ctx* ctx, const uint32_t* d_scalars, size_t base0,
     int cur = 0;
     auto step = [&](uint32_t d, uint32_t mode) {
       if constexpr (TE)
-        HIP_OK(LaunchTe::reduce_scan_step(bufs[cur], a_sums, bufs[cur ^ 1], nb, p.bucket_windows, d, mode, flags, st));
+        HIP_OK(LaunchTe::reduce_scan_step(bufs[cur], a_sums, bufs[cur ^ 1], nb, p.bucket_windows, d, mode, ctx->quad_limit, flags, st));
       else
-        HIP_OK(Launch<E>::reduce_scan_step(bufs[cur], a_sums, bufs[cur ^ 1], nb, p.bucket_windows, d, mode, st));
+        HIP_OK(Launch<E>::reduce_scan_step(bufs[cur], a_sums, bufs[cur ^ 1], nb, p.bucket_windows, d, mode, ctx->quad_limit, st));
       cur ^= 1;
     };
     for (uint32_t d = 1; d < nb; d <<= 1) step(d, 0);
@@ -764,8 +809,10 @@ void run_device_t(mi355_msm_ctx* ctx, uint8_t* out, const uint32_t* d_scalars, s
   using E = typename C::E;
   using Xyzz = XyzzT<typename E::T>;
   typename E::Md md;
+  // An allocation failure caps the chunks of THIS run only (one transient event -- fragmentation, another tenant's spike --
+  // must not cost every later MSM an extra bucket reduction): the next run plans against the memory that is free then.
   size_t max_chunk = ctx->opt_max_chunk ? (size_t)ctx->opt_max_chunk : ((size_t)1 << 26);
-  if (ctx->chunk_cap) max_chunk = std::min(max_chunk, ctx->chunk_cap);
+  ctx->chunk_cap = 0;
   const size_t out_bytes = 3 * 4 * E::WORDS;
   const size_t head = (hb && batches) ? first_piece_pairs(n, max_chunk) : 0;
   if (hb && batches && n) {
@@ -810,7 +857,7 @@ void run_device_t(mi355_msm_ctx* ctx, uint8_t* out, const uint32_t* d_scalars, s
         if (e.code != (int)hipErrorOutOfMemory || cn <= 1024) throw;
         (void)hipStreamSynchronize(st);
         release_work_buffers(ctx);
-        max_chunk = ctx->chunk_cap = (cn + 1) / 2;
+        max_chunk = ctx->chunk_cap = (cn + 1) / 2;   // for the rest of this run
         ctx->oom_backoffs++;
         continue;
       }
@@ -897,11 +944,12 @@ void run_host(mi355_msm_ctx* ctx, void* out, const void* scalars, size_t n, size
 }  // namespace
 
 #include "msm_sharded.hpp"
+#include "msm_stateless.hpp"
 
 extern "C" {
 
 RustError mi355_msm_create(mi355_msm_ctx** out, int curve, int device) {
-  return guarded([&] {
+  return guarded_dev([&] {
     if (!out) bad_arg("null context out-pointer");
     *out = nullptr;
     if (!known_curve(curve)) bad_arg("unknown curve id %d", curve);
@@ -929,7 +977,7 @@ RustError mi355_msm_create(mi355_msm_ctx** out, int curve, int device) {
 }
 
 RustError mi355_msm_destroy(mi355_msm_ctx* ctx) {
-  return guarded([&] {
+  return guarded_dev([&] {
     if (!ctx) return;
     if (!ctx->shards.empty()) {
       sharded_destroy(ctx);
@@ -938,7 +986,7 @@ RustError mi355_msm_destroy(mi355_msm_ctx* ctx) {
     }
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->own_stream);
-    DevBuf* bufs[] = {&ctx->bases, &ctx->inf, &ctx->scalars, &ctx->te_bases, &ctx->flags};
+    DevBuf* bufs[] = {&ctx->bases, &ctx->inf, &ctx->scalars, &ctx->te_bases, &ctx->flags, &ctx->stateless_raw[0], &ctx->stateless_raw[1], &ctx->stateless_raw[2]};
     for (DevBuf* b : bufs) b->release();
     release_work_buffers(ctx);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
@@ -954,7 +1002,7 @@ RustError mi355_msm_destroy(mi355_msm_ctx* ctx) {
 }
 
 RustError mi355_msm_create_sharded(mi355_msm_ctx** out, int curve, const int* devices, int ndevices) {
-  return guarded([&] {
+  return guarded_dev([&] {
     if (!out) bad_arg("null context out-pointer");
     *out = nullptr;
     if (!known_curve(curve)) bad_arg("unknown curve id %d", curve);
@@ -979,7 +1027,7 @@ RustError mi355_msm_create_env(mi355_msm_ctx** out, int curve) {
 }
 
 RustError mi355_msm_set_bases(mi355_msm_ctx* ctx, const void* affine, size_t npoints, size_t stride) {
-  return guarded([&] {
+  return guarded_dev([&] {
     if (!ctx) bad_arg("null context");
     if (npoints && !affine) bad_arg("null bases pointer");
     if (!ctx->shards.empty()) return sharded_set_bases(ctx, affine, npoints, stride, false, false);
@@ -988,7 +1036,7 @@ RustError mi355_msm_set_bases(mi355_msm_ctx* ctx, const void* affine, size_t npo
 }
 
 RustError mi355_msm_set_bases_serialized(mi355_msm_ctx* ctx, const void* records, size_t npoints) {
-  return guarded([&] {
+  return guarded_dev([&] {
     if (!ctx) bad_arg("null context");
     if (npoints && !records) bad_arg("null records pointer");
     const size_t stride = 2 * coord_bytes(ctx->curve);
@@ -1032,7 +1080,7 @@ RustError mi355_msm_point_to_serialized(int curve, const void* projective, void*
 }
 
 RustError mi355_msm_set_bases_device(mi355_msm_ctx* ctx, const void* d_affine, size_t npoints, size_t stride) {
-  return guarded([&] {
+  return guarded_dev([&] {
     if (!ctx) bad_arg("null context");
     if (npoints && !d_affine) bad_arg("null bases pointer");
     if (!ctx->shards.empty()) return sharded_set_bases(ctx, d_affine, npoints, stride, false, true);
@@ -1044,7 +1092,7 @@ RustError mi355_msm_set_bases_device(mi355_msm_ctx* ctx, const void* d_affine, s
 }
 
 RustError mi355_msm_run(mi355_msm_ctx* ctx, void* out, const void* scalars, size_t npoints, size_t batches) {
-  return guarded([&] {
+  return guarded_dev([&] {
     if (!ctx) bad_arg("null context");
     if (npoints * batches && !scalars) bad_arg("null scalars pointer");
     if (!ctx->shards.empty()) return sharded_run(ctx, out, scalars, npoints, batches, false, nullptr);
@@ -1054,7 +1102,7 @@ RustError mi355_msm_run(mi355_msm_ctx* ctx, void* out, const void* scalars, size
 
 RustError mi355_msm_run_device(mi355_msm_ctx* ctx, void* out, const void* d_scalars, size_t npoints, size_t batches,
                                void* stream) {
-  return guarded([&] {
+  return guarded_dev([&] {
     if (!ctx) bad_arg("null context");
     if (npoints * batches && !d_scalars) bad_arg("null scalars pointer");
     if (!ctx->shards.empty()) return sharded_run(ctx, out, d_scalars, npoints, batches, true, (hipStream_t)stream);
@@ -1100,9 +1148,9 @@ RustError mi355_msm_set_option(mi355_msm_ctx* ctx, const char* key, long value) 
       if (value != 0 && (value < 6 || value > 18)) bad_arg("reduce_scan_log %ld out of range [6, 18]", value);
       ctx->opt_reduce_scan_log = value;
     } else if (k == "quad_limit") {
-      // process-wide: launches of at most this many additions run four lanes per addition (twisted-Edwards merge / scan steps)
+      // launches of at most this many additions run four lanes per addition (merge / scan steps); a field of THIS context
       if (value < 0 || value > (1L << 24)) bad_arg("quad_limit %ld out of range [0, 2^24]", value);
-      LaunchTe::quad_limit = (uint32_t)value;
+      ctx->quad_limit = (uint32_t)value;
     } else if (k == "reduce_scan") {
       if (value < -1 || value > 1) bad_arg("reduce_scan %ld out of range [-1, 1]", value);
       ctx->opt_reduce_scan = value;
@@ -1124,8 +1172,8 @@ RustError mi355_msm_set_option(mi355_msm_ctx* ctx, const char* key, long value) 
       ctx->opt_mem_limit = value;
       ctx->chunk_cap = 0;
     } else if (k == "inject_alloc_failures") {
-      // test hook: the next `value` device allocations made by the calling thread fail with hipErrorOutOfMemory
-      g_inject_alloc_failures = value;
+      // test hook: the next `value` work-buffer reservations of this context (every shard of a sharded one) fail with hipErrorOutOfMemory
+      ctx->inject_alloc_failures = value;
     } else {
       bad_arg("unknown option '%s'", key);
     }
@@ -1144,6 +1192,22 @@ RustError mi355_msm_last_timings(mi355_msm_ctx* ctx, float* ms, uint64_t* info) 
     }
     if (ms) memcpy(ms, ctx->last_ms, sizeof ctx->last_ms);
     if (info) memcpy(info, ctx->last_info, sizeof ctx->last_info);
+  });
+}
+
+RustError mi355_msm_shard_timings(mi355_msm_ctx* ctx, int shard, float* ms, uint64_t* info) {
+  return guarded([&] {
+    if (!ctx) bad_arg("null context");
+    if (ctx->shards.empty()) {
+      if (shard != 0) bad_arg("shard %d of an unsharded context", shard);
+      if (ms) memcpy(ms, ctx->last_ms, sizeof ctx->last_ms);
+      if (info) memcpy(info, ctx->last_info, sizeof ctx->last_info);
+      return;
+    }
+    if (shard < 0 || (size_t)shard >= ctx->shards.size()) bad_arg("shard %d of %zu", shard, ctx->shards.size());
+    const mi355_msm_ctx* sh = ctx->shards[(size_t)shard];
+    if (ms) memcpy(ms, sh->last_ms, sizeof sh->last_ms);
+    if (info) memcpy(info, sh->last_info, sizeof sh->last_info);
   });
 }
 
@@ -1202,14 +1266,85 @@ RustError mi355_msm_query(mi355_msm_ctx* ctx, const char* key, uint64_t* value) 
 }
 
 RustError mi355_msm(int curve, void* out, const void* affine, size_t npoints, const void* scalars, size_t ffi_affine_sz) {
-  mi355_msm_ctx* ctx = nullptr;
-  RustError e = mi355_msm_create_env(&ctx, curve);
-  if (e.code) return e;
-  e = mi355_msm_set_bases(ctx, affine, npoints, ffi_affine_sz);
-  if (!e.code) e = mi355_msm_run(ctx, out, scalars, npoints, 1);
-  RustError d = mi355_msm_destroy(ctx);
-  if (d.code) free(d.message);
-  return e;
+  // both operands stream out of the caller's (pageable) memory while earlier slices compute: msm_stateless.hpp
+  return guarded_dev([&] {
+    if (!known_curve(curve)) bad_arg("unknown curve id %d", curve);
+    if (!out) bad_arg("null output pointer");
+    // MI355_MSM_DEVICES = "0,1,2,3" | "0-7" | "all" | unset: several GPUs -> one pipeline per shard over its slice of both operands
+    std::vector<int> devs{-1};
+    const char* env = getenv("MI355_MSM_DEVICES");
+    if (env && *env) {
+      try {
+        devs = parse_device_list(env);
+      } catch (const std::exception& e) {
+        throw HipFailure(-1, e.what());
+      }
+    }
+    const size_t G = devs.size(), pb = 3 * coord_bytes(curve);
+    if (G == 1) {
+      StatelessLease ws(curve, devs[0]);
+      stateless_run(ws.ctx, out, affine, npoints, scalars, ffi_affine_sz);
+      ws.keep();
+      return;
+    }
+    std::vector<uint8_t> partials(G * pb);
+    std::vector<std::string> errors(G);
+    std::vector<int> codes(G, 0);
+    std::vector<StatelessStats> stats(G);
+    std::vector<std::thread> threads;
+    for (size_t g = 0; g < G; g++)
+      threads.emplace_back([&, g] {
+        try {
+          size_t lo, hi;
+          shard_bounds(npoints, G, g, lo, hi);
+          StatelessLease ws(curve, devs[g]);
+          stateless_run(ws.ctx, partials.data() + g * pb, (const uint8_t*)affine + lo * ffi_affine_sz, hi - lo, (const uint8_t*)scalars + lo * 32,
+                        ffi_affine_sz);
+          ws.keep();
+          stats[g] = g_last_stateless;
+        } catch (const HipFailure& e) {
+          codes[g] = e.code ? e.code : -1;
+          errors[g] = e.what();
+        } catch (const std::exception& e) {
+          codes[g] = -1;
+          errors[g] = e.what();
+        }
+      });
+    for (auto& t : threads) t.join();
+    for (size_t g = 0; g < G; g++)
+      if (codes[g]) throw HipFailure(codes[g], "shard " + std::to_string(g) + " (device " + std::to_string(devs[g]) + "): " + errors[g]);
+    take(mi355_msm_fold(curve, out, partials.data(), G));
+    g_last_stateless = *std::max_element(stats.begin(), stats.end(), [](const StatelessStats& a, const StatelessStats& b) { return a.total_ms < b.total_ms; });
+  });
+}
+
+RustError mi355_msm_last_stateless(double* out, size_t count) {
+  return guarded([&] {
+    if (!out) bad_arg("null output");
+    const StatelessStats& s = g_last_stateless;
+    const double v[8] = {s.total_ms, s.setup_ms, s.wait_upload_ms, s.compute_ms, s.tail_ms, s.slices, s.threads, s.bytes};
+    for (size_t i = 0; i < count && i < 8; i++) out[i] = v[i];
+  });
+}
+
+RustError mi355_msm_trim(void) {
+  return guarded_dev([&] {
+    std::vector<StageRing*> rings;
+    std::vector<mi355_msm_ctx*> idle;
+    {
+      std::lock_guard<std::mutex> lk(g_ring_mu);
+      rings.swap(g_rings_idle);
+      idle.swap(g_stateless_idle);
+    }
+    for (StageRing* r : rings) {
+      (void)hipSetDevice(r->device);
+      ring_destroy(r);
+    }
+    for (mi355_msm_ctx* c : idle) {
+      RustError d = mi355_msm_destroy(c);
+      if (d.message) free(d.message);
+    }
+  });
 }
 
 RustError mi355_msm_fold(int curve, void* out, const void* projective, size_t count) {

@@ -9,11 +9,13 @@
 //   set_bases   shard g receives the contiguous slice [g*ceil(n/G), ...) of the bases, uploaded concurrently (one host thread
 //               per device);
 //   run         every shard runs the full single-device pipeline on its slice of every scalar batch and yields one partial
-//               point per batch;  the G partials are exchanged by ONE ncclAllGather of G x batches x 144 B over RCCL/xGMI
-//               (single-process communicator, ncclCommInitAll) and folded on the host ("the final 8-point curve add").
-//               Elliptic-curve addition is not an RCCL reduction operator, hence gather-then-fold.  The partials are
-//               already in host memory when the shards return, so the host fold of exactly those bytes is both the fallback
-//               (librccl not loadable, the same device listed twice) and the checker of the exchanged copy.
+//               point per batch, which its host thread has ALREADY folded out of W window sums on the host -- so in this
+//               one-process form the G partials are in host memory when the shards return and "the final 8-point curve add"
+//               is a host fold of G x batches x 144 B.  No collective is needed for that, and none is run by default.
+//               Option "combine" = 2 additionally routes the partials through ONE ncclAllGather over RCCL/xGMI
+//               (single-process communicator, ncclCommInitAll at set_bases) and requires the exchanged copy to equal what
+//               was sent: a link check for bring-up on a new node, not a step the result depends on.  The collective that IS
+//               needed -- partials living in different processes -- is dist.py's all_gather (one process per GPU).
 //
 // `devices` may name a device more than once (logical shards on one GPU): that is how the 2^28 / 8-shard workload is rehearsed
 // on a one-GPU box.
@@ -212,6 +214,8 @@ static int pointer_device(const void* p) {
   return attr.type == hipMemoryTypeDevice ? attr.device : -1;
 }
 
+static bool rccl_ready(mi355_msm_ctx* ctx, size_t payload);
+
 // Bases for the whole sharded context: host memory (or CanonicalSerialize records), or ONE device buffer (any device: a shard
 // on another GPU pulls its slice over xGMI into a staging buffer first).
 static void sharded_set_bases(mi355_msm_ctx* ctx, const void* data, size_t n, size_t stride, bool serialized, bool on_device) {
@@ -255,6 +259,7 @@ static void sharded_set_bases(mi355_msm_ctx* ctx, const void* data, size_t n, si
     stage.release();
   });
   ctx->nbases = n;
+  if (ctx->opt_combine == 2) (void)rccl_ready(ctx, 3 * coord_bytes(ctx->curve));   // communicator + buffers now, not inside the first run
 }
 
 static bool devices_distinct(const mi355_msm_ctx* ctx) {
@@ -264,9 +269,10 @@ static bool devices_distinct(const mi355_msm_ctx* ctx) {
   return true;
 }
 
-// Lazily: load librccl, ncclCommInitAll over the shard devices, per-shard send/recv buffers.  false = fall back to the host fold.
+// combine = 2 only: load librccl, ncclCommInitAll over the shard devices (first called from set_bases, so that the
+// communicator is not built inside a timed run), per-shard send/recv buffers.  false = host fold only.
 static bool rccl_ready(mi355_msm_ctx* ctx, size_t payload) {
-  if (ctx->opt_combine == 1) return false;
+  if (ctx->opt_combine != 2) return false;
   if (!ctx->rccl) {
     ctx->rccl = new RcclState();
     RcclState& r = *ctx->rccl;

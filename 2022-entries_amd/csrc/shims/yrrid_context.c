@@ -2,7 +2,9 @@
  * int32 status: 0 = ok, otherwise the failing call's error code; the status is sticky like CMB MSM.cu:44,401-402.
  * The reference's preconditions (points % 65536 == 0, batches <= 16: CMB MSM.cu:364-372, 404-417) do not apply here. */
 #define MI355_SHIM_YRRID
+#include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include "../../../include/mi355_msm_shims.h"
 
@@ -51,4 +53,57 @@ int32_t MSMRun(void* context, uint64_t* projectiveResultsPtr, void* scalarsPtr, 
   if (y->error_state) return y->error_state;
   if (y->points == 0 || scalars % y->points != 0) return y->error_state = -1;
   return take(y, mi355_msm_run(y->ctx, projectiveResultsPtr, scalarsPtr, y->points, scalars / y->points));
+}
+
+/* ---- hex readers (CMB MSM.h:68-69) ------------------------------------------------------------------------------------
+ * One token: skip white space, take hex digits up to the next white space or end of file; more than 2 * width digits or any
+ * other character is an error.  The digits are most-significant first; the value is stored little-endian in `width` bytes. */
+static int hex_value(int c) {
+  if (c >= '0' && c <= '9') return c - '0';
+  if (c >= 'a' && c <= 'f') return c - 'a' + 10;
+  if (c >= 'A' && c <= 'F') return c - 'A' + 10;
+  return -1;
+}
+
+static int is_space(int c) { return c == ' ' || c == '\t' || c == '\n' || c == '\r'; }
+
+static int read_hex_token(FILE* f, uint8_t* out, int width) {
+  char digits[2 * 96];
+  int n = 0, c = getc(f);
+  while (is_space(c)) c = getc(f);
+  if (c == EOF) return 0;
+  while (c != EOF && !is_space(c)) {
+    if (hex_value(c) < 0 || n >= 2 * width) return 0;
+    digits[n++] = (char)c;
+    c = getc(f);
+  }
+  memset(out, 0, (size_t)width);
+  for (int i = 0; i < n; i++) {   /* digit i from the END is nibble i of the little-endian image */
+    const int v = hex_value(digits[n - 1 - i]);
+    out[i / 2] |= (uint8_t)((i & 1) ? v << 4 : v);
+  }
+  return 1;
+}
+
+int32_t MSMReadHexPoints(uint8_t* pointsPtr, uint32_t count, const char* path) {
+  FILE* f = (pointsPtr && path) ? fopen(path, "r") : NULL;
+  if (!f) return -1;
+  int32_t rc = 0;
+  for (uint32_t i = 0; i < count && rc == 0; i++) {
+    uint8_t* rec = pointsPtr + (size_t)i * 104;
+    if (!read_hex_token(f, rec, 48) || !read_hex_token(f, rec + 48, 48)) rc = -1;
+    memset(rec + 96, 0, 8);
+  }
+  fclose(f);
+  return rc;
+}
+
+int32_t MSMReadHexScalars(uint8_t* scalarsPtr, uint32_t count, const char* path) {
+  FILE* f = (scalarsPtr && path) ? fopen(path, "r") : NULL;
+  if (!f) return -1;
+  int32_t rc = 0;
+  for (uint32_t i = 0; i < count && rc == 0; i++)
+    if (!read_hex_token(f, scalarsPtr + (size_t)i * 32, 32)) rc = -1;
+  fclose(f);
+  return rc;
 }

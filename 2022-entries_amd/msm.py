@@ -91,12 +91,15 @@ def load_library() -> ctypes.CDLL:
         "mi355_msm_set_option": [vp, ctypes.c_char_p, ctypes.c_long],
         "mi355_msm_last_timings": [vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_uint64)],
         "mi355_msm_query": [vp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_uint64)],
+        "mi355_msm_shard_timings": [vp, ci, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_uint64)],
         "mi355_msm": [ci, vp, vp, sz, vp, sz],
         "mi355_msm_fold": [ci, vp, vp, sz],
         "mi355_msm_generate_points": [ci, ctypes.c_uint64, sz, sz, vp, sz],
         "mi355_msm_plan": [ci, sz, ci, ctypes.POINTER(ctypes.c_long), ctypes.POINTER(ctypes.c_uint64)],
         "mi355_msm_set_bases_serialized": [vp, vp, sz],
         "mi355_msm_point_to_serialized": [ci, vp, vp],
+        "mi355_msm_last_stateless": [ctypes.POINTER(ctypes.c_double), sz],
+        "mi355_msm_trim": [],
     }
     for name, args in sigs.items():
         fn = getattr(lib, name)
@@ -266,6 +269,18 @@ class MultiScalarMultContext:
                  launches=int(info[4]), lanes=int(info[5]), tables=bool(info[6]), twisted_edwards=bool(info[7]))
         return d
 
+    def shard_timings(self) -> list:
+        """Per-shard stage times of the most recent run (one entry for an unsharded context)."""
+        out = []
+        for g in range(max(1, self.query("shards"))):
+            ms = (ctypes.c_float * 8)()
+            info = (ctypes.c_uint64 * 8)()
+            _check(self._lib.mi355_msm_shard_timings(self.context, g, ms, info))
+            d = {name: float(ms[i]) for i, name in enumerate(T_NAMES)}
+            d.update(shard=g, window_bits=int(info[0]), entries=int(info[2]), launches=int(info[4]))
+            out.append(d)
+        return out
+
     def close(self) -> None:
         if self.context:
             _check(self._lib.mi355_msm_destroy(self.context))
@@ -306,18 +321,27 @@ def msm(bases, scalars, curve="bls12_377_g1") -> bytes:
     nb = _Buf(bases).nbytes // stride
     ns = _Buf(scalars).nbytes // SCALAR_BYTES
     n = min(nb, ns)
+    pb, sb = _Buf(bases), _Buf(scalars)
+    if not (pb.is_device or sb.is_device):
+        # both operands in host memory: the stateless C entry (a pipeline: slices cross PCIe while earlier ones compute)
+        out = ctypes.create_string_buffer(projective_bytes(curve))
+        _check(load_library().mi355_msm(_curve_id(curve), out, pb.ptr, n, sb.ptr, stride))
+        return out.raw
     ctx = MultiScalarMultContext(curve)
     try:
-        pb, sb = _Buf(bases), _Buf(scalars)
-        if pb.is_device or sb.is_device:
-            # chop BYTES, not rows: the inputs are usually 2-D (N, 104) / (N, 32) tensors
-            ctx.set_bases(_flat_bytes(bases)[: n * stride])
-            return ctx.run(_flat_bytes(scalars)[: n * SCALAR_BYTES], n)[0]
-        out = ctypes.create_string_buffer(projective_bytes(curve))
-        _check(ctx._lib.mi355_msm(ctx.curve, out, pb.ptr, n, sb.ptr, stride))
-        return out.raw
+        # chop BYTES, not rows: the inputs are usually 2-D (N, 104) / (N, 32) tensors
+        ctx.set_bases(_flat_bytes(bases)[: n * stride])
+        return ctx.run(_flat_bytes(scalars)[: n * SCALAR_BYTES], n)[0]
     finally:
         ctx.close()
+
+
+def last_stateless() -> dict:
+    """What this thread's most recent stateless ``msm`` call did (mi355_msm_last_stateless)."""
+    v = (ctypes.c_double * 8)()
+    _check(load_library().mi355_msm_last_stateless(v, 8))
+    names = ("total_ms", "setup_ms", "wait_upload_ms", "compute_ms", "tail_ms", "slices", "threads", "bytes")
+    return {k: float(v[i]) for i, k in enumerate(names)}
 
 
 class VariableBaseMSM:

@@ -6,10 +6,14 @@
 
 A "step" is one MSM of 2^npow point-scalar pairs per GPU (default 2^26, BASELINE.json configs[1]) with the bases
 AND the scalars already resident in HBM: device scalars -> digits -> sort -> bucket accumulation -> bucket reduction ->
-window sums to the host -> Horner fold; with N > 1 ranks each rank owns a disjoint slice (weak scaling: 2^npow pairs
-per GPU), the N 144-byte partials are all-gathered with RCCL and folded on every rank.  Rank 0 prints ONE JSON line.
+window sums to the host -> Horner fold; with N > 1 ranks each rank owns a disjoint slice, the N 144-byte partials are
+all-gathered with RCCL and folded on every rank.  Rank 0 prints ONE JSON line.
 
-`roofline` is for the dominant kernel (bucket accumulation, k_accumulate_coop): algorithmic bytes = 128 B/pair
+Workload per N: N = 1, 2, 4 -> 2^26 pairs per GPU (weak scaling from BASELINE configs[1]); N = 8 -> BASELINE configs[3], the
+2^28-pair MSM sharded 8 ways (2^25 per GPU), with the 2^26-per-GPU weak-scaling point measured in the same run as a
+secondary object.  `--total-npow T` fixes the GLOBAL size for any N (per GPU: 2^T / N).
+
+`roofline` is for the dominant kernel (bucket accumulation, k_accumulate_glds): algorithmic bytes = 128 B/pair
 (32 B scalar + 96 B affine base) x pairs per launch, over its HIP-event duration on the launch stream.
 `cpu_baseline` times oracle/liboracle.so -- the C restatement of arkworks' VariableBaseMSM, one thread per window like
 rayon -- on a bounded sample of the same workload, rank 0, N = 1 only.  It is a reported baseline, not the target.
@@ -94,6 +98,9 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--npow", type=int, default=26, help="log2 pairs per GPU (26 = ZPrize prize1-msm canonical size)")
+    ap.add_argument("--total-npow", type=int, default=-1,
+                    help="log2 pairs of the WHOLE job, split evenly over the GPUs (overrides --npow); default: 28 when --gpus 8 "
+                         "(BASELINE.json configs[3]), otherwise unset (2^npow per GPU); 0 = never")
     ap.add_argument("--curve", default="bls12_377_g1", choices=["bls12_377_g1", "bls12_381_g1", "bls12_377_g2"])
     ap.add_argument("--cpu-sample-pow", type=int, default=26,
                     help="log2 pairs of the CPU-baseline sample (0 = skip); 26 = the whole workload once, about a minute of host time")
@@ -139,6 +146,16 @@ def main():
     coll_device = device if args.backend == "nccl" else None
 
     cid = ea.CURVE_IDS[args.curve]
+    n_ranks = args.gpus if c_sharded else world
+    total_npow = args.total_npow
+    if total_npow < 0:
+        total_npow = 28 if (n_ranks == 8 and args.curve == "bls12_377_g1" and args.npow == 26) else 0
+    weak_secondary = None
+    if total_npow:
+        if n_ranks & (n_ranks - 1) or (1 << total_npow) < n_ranks:
+            raise SystemExit("--total-npow needs a power-of-two number of GPUs")
+        weak_secondary = args.npow if args.total_npow < 0 else None      # the default N = 8 line also carries the weak-scaling point
+        args.npow = total_npow - (n_ranks.bit_length() - 1)
     n = 1 << args.npow
     distinct = min(n, 1 << 15)
     # synthetic inputs in the reference generator's shape: 2^15 distinct subgroup points replicated to n,
@@ -196,10 +213,59 @@ def main():
             stage_ms[k] = stage_ms.get(k, 0.0) + tm[k]
     fence()
     elapsed = time.perf_counter() - t0
+    per_rank = None
     if world > 1:
+        my_elapsed = elapsed
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+        # per-rank wall and stage times, so that an imbalance between the shards is visible in the line
+        mine = {"rank": rank, "device": local_rank, "ms_per_step": my_elapsed / args.steps * 1e3,
+                "stage_ms_per_step": {k: v / args.steps for k, v in stage_ms.items()}}
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        per_rank = gathered
+    elif c_sharded:
+        per_rank = ctx.shard_timings()
+
+    weak_point = None
+    if weak_secondary is not None:
+        # the weak-scaling point (2^26 pairs per GPU, what N = 1, 2, 4 measure) next to the configs[3] headline
+        try:
+            ctx.close()
+            nw = 1 << weak_secondary
+            if c_sharded:
+                ctxw = ea.MultiScalarMultContext(args.curve, devices=devs)
+                ctxw.set_bases(tile.repeat(nw // distinct, 1).repeat(args.gpus, 1))
+                scw = torch.cat([uniform_scalars(nw, R377_TOP, device, seed=1234 + g) for g in range(args.gpus)])
+            else:
+                ctxw = ea.MultiScalarMultContext(args.curve, device=local_rank)
+                ctxw.set_bases(tile.repeat(nw // distinct, 1).contiguous())
+                scw = uniform_scalars(nw, R377_TOP, device, seed=1234 + rank)
+
+            def stepw():
+                partial = ctxw.run(scw)[0]
+                if world > 1:
+                    return ea.fold_partials(ea.all_gather_partials(partial, device=coll_device), args.curve)
+                return partial
+
+            stepw()
+            fence()
+            tw = time.perf_counter()
+            for _ in range(args.steps):
+                stepw()
+            fence()
+            tw = time.perf_counter() - tw
+            if world > 1:
+                tmax = torch.tensor([tw], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
+                dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+                tw = float(tmax.item())
+            weak_point = {"workload": f"{args.curve} MSM, 2^{weak_secondary} pairs per GPU (weak scaling from the N = 1 line)",
+                          "value": nw * n_ranks * args.steps / tw, "unit": "pairs/s", "ms_per_step": tw / args.steps * 1e3, "scaling": "weak"}
+            ctxw.close()
+            del scw
+        except Exception as e:
+            weak_point = {"error": repr(e)}
 
     if rank == 0:
         pairs_per_step = n * world * (args.gpus if c_sharded else 1)
@@ -244,12 +310,14 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3,
             "ms_per_2^26_pairs": elapsed / args.steps * 1e3 * (1 << 26) / n,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "weak" if not total_npow else "strong",
             "vs_baseline": None,
             "dtype": "u32",
             "dtype_detail": "14 x 28-bit limbs in u32 lanes, Montgomery radix 2^392, products accumulated in u64 (v_mad_u64_u32)",
             "data": "synthetic: 2^15 distinct subgroup points replicated (reference generator shape), uniform scalars < r",
-            "config": {"workload": f"{args.curve} MSM, 2^{args.npow} pairs per GPU, bases+scalars resident in HBM",
+            "config": {"workload": (f"{args.curve} MSM, 2^{total_npow} pairs sharded over {n_ranks} GPU(s) (2^{args.npow} per GPU; BASELINE.json configs[3] at N = 8), "
+                                    f"bases+scalars resident in HBM" if total_npow else
+                                    f"{args.curve} MSM, 2^{args.npow} pairs per GPU, bases+scalars resident in HBM"),
                        "pairs_per_gpu": n, "window_bits": tm["window_bits"], "windows": tm["windows"],
                        "lane_entries": tm["lane_entries"], "precompute": bool(args.precompute),
                        "group_law": "extended twisted Edwards (7M mixed add)" if ctx.query("twisted_edwards") else "XYZZ (8M+2S mixed add)",
@@ -258,6 +326,8 @@ def main():
                                        f"{'RCCL all-gather' if ctx.query('rccl_exchanges') else 'host fold'} of {args.gpus} partial points" if c_sharded else
                                        f"{world} disjoint base/scalar slices + all-gather of {world} partial points")},
             "stage_ms_per_step": {k: v / args.steps for k, v in stage_ms.items()},
+            "per_rank": per_rank,
+            "weak_scaling_point": weak_point,
             "roofline": {"bound": "hbm", "kernel": "k_accumulate_glds", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_from": traffic_from,
                          "kernel_ms": kern_s * 1e3, "algorithmic_bytes_per_launch": BYTES_PER_PAIR[cid] * pairs_per_launch,
@@ -299,14 +369,32 @@ def main():
                     extras["xyzz_same_result"] = rx == result
                     cx.close()
                 # one stateless call: host bases -> upload -> conversion (+ twisted-Edwards image) -> MSM -> teardown
+                # (a pipeline since round 3: slices cross PCIe through a pinned ring while earlier ones compute, csrc/msm_stateless.hpp)
                 bases_host = np.ascontiguousarray(np.tile(base_tile, (n // distinct, 1)))
                 t_s = time.perf_counter()
                 rs = ea.msm(bases_host, sc_np, args.curve)
-                extras["stateless_ms"] = (time.perf_counter() - t_s) * 1e3
-                extras["stateless_same_result"] = rs == result
-                extras["stateless_what"] = "mi355_msm(): %.1f GB of bases and %.1f GB of scalars from pageable host memory, everything included" % (
-                    bases_host.nbytes / 1e9, sc_np.nbytes / 1e9)
-                del bases_host
+                extras["stateless_first_ms"] = (time.perf_counter() - t_s) * 1e3     # first call of the process: allocates the pinned ring
+                first_stats = ea.last_stateless()
+                warm = []
+                for _ in range(3):
+                    t_s = time.perf_counter()
+                    rs2 = ea.msm(bases_host, sc_np, args.curve)
+                    warm.append((time.perf_counter() - t_s) * 1e3)
+                warm.sort()
+                extras["stateless_ms"] = warm[1]
+                extras["stateless_ms_all"] = warm
+                # operands the process has never touched through HIP before (fresh pages): what a cold caller sees
+                bases_cold = bases_host.copy()
+                sc_cold = sc_np.copy()
+                t_s = time.perf_counter()
+                rs3 = ea.msm(bases_cold, sc_cold, args.curve)
+                extras["stateless_fresh_operands_ms"] = (time.perf_counter() - t_s) * 1e3
+                extras["stateless_pipeline"] = {"first_call": first_stats, "fresh_operands": ea.last_stateless()}
+                extras["stateless_same_result"] = rs == result and rs2 == result and rs3 == result
+                extras["stateless_what"] = ("mi355_msm(): %.1f GB of bases and %.1f GB of scalars from pageable host memory, everything included "
+                                            "(upload, conversion, MSM on the XYZZ law, teardown)") % (bases_host.nbytes / 1e9, sc_np.nbytes / 1e9)
+                extras["stateless_pcie_floor_ms"] = (bases_host.nbytes + sc_np.nbytes) / 57e9 * 1e3
+                del bases_host, bases_cold, sc_cold
                 out["survey_8d_metrics"] = extras
             except Exception as e:   # never lose the headline line to a secondary measurement
                 out["survey_8d_metrics"] = {"error": repr(e)}

@@ -77,11 +77,13 @@ RustError mi355_msm_destroy(mi355_msm_ctx* ctx);
  * is an ordinary mi355_msm_ctx*: set_bases / set_bases_device / set_bases_serialized / run / run_device / set_option / query /
  * last_timings / destroy all accept it.  Shard g of G owns the contiguous slice [g*ceil(n/G), ...) of the bases and of every
  * scalar batch, one host thread + one device context + one stream per shard (the multi-stream orchestration of
- * P1A matter-labs/src/lib.rs:125-201 with devices in place of streams); the G partial points per batch are exchanged by one
- * ncclAllGather over RCCL/xGMI (single-process communicator; librccl is dlopen'ed) and folded on the host -- elliptic-curve
- * addition is not an RCCL reduction operator.  The host fold of the shards' own outputs is the fallback (no librccl, or a
- * device listed twice = logical shards on one GPU) and checks the exchanged copy.  Option "combine": 0 auto, 1 host fold only,
- * 2 require RCCL.  Queries: "shards", "rccl_exchanges"; counters of the single-device queries add up over the shards. */
+ * P1A matter-labs/src/lib.rs:125-201 with devices in place of streams); each shard's host thread returns one folded partial
+ * point per batch, so the G partials are already in host memory and the "final 8-point curve add" is a host fold
+ * (mi355_msm_fold) -- no collective is run by default.  Option "combine" = 2 additionally sends the partials through one
+ * ncclAllGather over RCCL/xGMI (single-process communicator, built at set_bases; librccl is dlopen'ed) and requires the
+ * exchanged copy to equal what was sent: a link check for bring-up, not a step the result depends on (0 / 1: host fold only).
+ * The collective that IS needed -- partials in different processes -- is the one-process-per-GPU path (dist.py, torchrun).
+ * Queries: "shards", "rccl_exchanges"; counters of the single-device queries add up over the shards. */
 RustError mi355_msm_create_sharded(mi355_msm_ctx** out, int curve, const int* devices, int ndevices);
 /* What the harness shims call: MI355_MSM_DEVICES = "0,1,2,3" | "0-7" | "all" selects a sharded context over those devices,
  * one entry (or unset) an ordinary one.  mi355_msm() (stateless) goes through here as well. */
@@ -119,7 +121,7 @@ RustError mi355_msm_run_device(mi355_msm_ctx* ctx, void* out_projective, const v
  * "reduce_log_chunk0" 1..7: bucket-reduction chunk sizes on all / the first level); 0 restores the automatic choice.
  * "reduce_scan" = 0 keeps the bucket reduction on the recursive chunked scheme only (default: its tail is a parallel scan);
  * "reduce_scan_log" 6..18 = log2 of the elements per window at which the scan takes over (default 12).
- * "quad_limit" (process-wide, default 2^18): merge / scan launches of at most that many additions spread each
+ * "quad_limit" (per context, default 2^18): merge / scan launches of at most that many additions spread each
  * addition over four lanes (latency); 0 = always one lane per addition.
  * Test hooks: "mem_limit" (bytes of device memory chunks may be planned against), "inject_alloc_failures".
  * "scalars_montgomery" = 1 makes every run treat the scalars as arkworks `Fr` values (Montgomery form, a*2^256 mod r)
@@ -146,6 +148,9 @@ RustError mi355_msm_query(mi355_msm_ctx* ctx, const char* key, uint64_t* value);
  * Chunks are sized to the device memory that is free (the reference plans its allocations first, ML msm.cu:453-466), and a
  * chunk whose allocation fails all the same is retried at half the size. */
 RustError mi355_msm_last_timings(mi355_msm_ctx* ctx, float* ms, uint64_t* info);
+/* The same for ONE shard of a sharded context (mi355_msm_last_timings reports the slowest shard per stage): an imbalance
+ * between the devices shows here.  shard 0 of an ordinary context is the context itself. */
+RustError mi355_msm_shard_timings(mi355_msm_ctx* ctx, int shard, float* ms, uint64_t* info);
 
 /* ---- stateless calls ---------------------------------------------------------------------------
  * sppark's mult_pippenger_inf(out, points, npoints, scalars, ffi_affine_sz)
@@ -153,6 +158,17 @@ RustError mi355_msm_last_timings(mi355_msm_ctx* ctx, float* ms, uint64_t* info);
  * `msm(bases, scalars, n)` is mi355_msm(curve, out, bases, n, scalars, 104). */
 RustError mi355_msm(int curve, void* out_projective, const void* affine, size_t npoints, const void* scalars,
                     size_t ffi_affine_sz);
+/* The call is a pipeline, as in the reference (SPK msm/pippenger.cuh:617-661 uploads the next slice of points and scalars
+ * while the current one is sorted and accumulated; CMB MSM.cu:419-434; the growing chunks of P1A matter-labs/src/lib.rs:171-182):
+ * slices of 2^20..2^23 pairs are staged by a few host threads through a small ring of pinned buffers (kept for the life of the
+ * process; mi355_msm_trim() gives it back) and cross PCIe while earlier slices are converted and run; partial sums are added
+ * on the host.  Environment: MI355_MSM_STAGE_THREADS (default 6), MI355_MSM_STATELESS_SLICE_LOG (log2 pairs per slice).
+ * With MI355_MSM_DEVICES naming several GPUs every shard runs its own pipeline over its slice of both operands.
+ * mi355_msm_last_stateless: what the calling thread's most recent stateless call did -- out[0..7] = total ms, setup ms (buffers,
+ * ring, threads), ms the compute side waited for uploads, ms it spent issuing/awaiting slices, the last slice's share of that
+ * (the tail nothing overlaps), slices, staging threads, bytes moved. */
+RustError mi355_msm_last_stateless(double* out, size_t count);
+RustError mi355_msm_trim(void);
 
 /* Sum `count` projective images (any Z) into one normalised image: the multi-GPU combine step
  * ("final 8-point curve add").  Pure host arithmetic on <= a few dozen points; no device needed. */
