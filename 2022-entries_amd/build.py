@@ -2,6 +2,7 @@
 
   libmi355msm.so       hipcc --offload-arch=gfx950: kernels + engine + C ABI (the product)
   libmsm_hosttest.so   g++: the same fp28/curve templates for the host with the limb-bound checker (tests only)
+  libmsm_devtest.so    hipcc: the same templates as element-wise test kernels (tests only)
   oracle/liboracle.so  gcc: CPU restatement of the arkworks algorithm (tests / smoke / bench cpu_baseline only)
   oracle/_ref/*        reference-derived cross-checks, only when /root/reference exists
 """
@@ -73,6 +74,16 @@ def build_hosttest(force: bool = False) -> str:
     return out
 
 
+def build_devtest(force: bool = False) -> str:
+    """libmsm_devtest.so (tests only): the arithmetic ops of csrc/devtest_ops.hpp as gfx950 kernels, one thread per raw limb record
+    (tests/test_gpu_devtest.py compares them limb for limb with the host build of the same templates)."""
+    out = os.path.join(PKG, "libmsm_devtest.so")
+    deps = [f for f in glob.glob(os.path.join(CSRC, "*")) if os.path.isfile(f) and (f.endswith(".hpp") or f.endswith(".inc") or f.endswith("devtest.hip"))]
+    if force or _newer(out, deps):
+        _run([hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-shared", "-o", out, os.path.join(CSRC, "devtest.hip")])
+    return out
+
+
 def build_shims(force: bool = False) -> list:
     """Harness-named symbol sets (include/mi355_msm_shims.h): tiny C objects linked against libmi355msm.so."""
     outs = []
@@ -98,6 +109,7 @@ def build_oracle() -> str:
 def build_all(force: bool = False) -> None:
     build_engine(force)
     build_hosttest(force)
+    build_devtest(force)
     build_shims(force)
     build_oracle()
 

@@ -435,3 +435,68 @@ extern "C" int ht_fold_both(int curve, const uint8_t* pts, size_t stride, const 
   if (curve == 2) return te ? 1 : t_fold_both<Bls12_377_G2>(pts, stride, mult, windows, c, 0, out_generic, out_fold64);
   return t_fold_both<Bls12_377_G1>(pts, stride, mult, windows, c, te, out_generic, out_fold64);
 }
+
+// ---- the op table of devtest_ops.hpp on the host: the twin of libmsm_devtest.so's msm_devtest_run ------------------------
+// Same raw limb records in, same limbs out (the device build replaces the portable multiply loops, the Montgomery step and
+// the selects with GCN assembly); MSM_CHECK is armed here, so a record that would overflow a 64-bit column or underflow a
+// biased subtraction is caught on this side.
+#include "devtest_ops.hpp"
+
+template <class C, bool TE>
+static int t_devop(int op, const uint32_t* in, int iw, uint32_t* out, int ow, size_t n) {
+  for (size_t i = 0; i < n; i++) {
+    const uint32_t* a = in + i * iw;
+    uint32_t* r = out + i * ow;
+    switch (op) {
+#define DT_CASE(OP) case OP: devtest_apply<C, OP>(a, r); break;
+      DT_CASE(DT_FE_MUL)
+      DT_CASE(DT_FE_SQR)
+      DT_CASE(DT_FE_MUL2)
+      DT_CASE(DT_NOT_AND_LMASK)
+      DT_CASE(DT_FE_WEAK_REDUCE)
+      DT_CASE(DT_EL_MUL)
+      DT_CASE(DT_EL_SQR)
+      DT_CASE(DT_EL_MUL_C)
+      DT_CASE(DT_EL_MUL_C_BIG)
+      DT_CASE(DT_EL_SQR_C)
+      DT_CASE(DT_EL_MUL_SUB_C)
+      DT_CASE(DT_MADD_COMMON)
+      DT_CASE(DT_MADD)
+      DT_CASE(DT_ADD)
+      DT_CASE(DT_DBL)
+      default:
+        if constexpr (TE) {
+          switch (op) {
+            DT_CASE(DT_TE_MADD)
+            DT_CASE(DT_TE_MADD_SWAPPED)
+            DT_CASE(DT_TE_ADD)
+            DT_CASE(DT_TE_DBL)
+            default: return -1;
+          }
+        } else {
+          return -1;
+        }
+#undef DT_CASE
+    }
+  }
+  return 0;
+}
+
+extern "C" int ht_devop(int curve, int op, const uint32_t* in, uint32_t* out, size_t n) {
+  int iw = 0, ow = 0;
+  if (curve < 0 || curve > 2 || !in || !out) return -1;
+  devtest_shape(op, curve == 2 ? 2 * NL : NL, iw, ow);
+  if (!iw) return -1;
+  switch (curve) {
+    case 0: return t_devop<Bls12_377_G1, true>(op, in, iw, out, ow, n);
+    case 1: return t_devop<Bls12_381_G1, false>(op, in, iw, out, ow, n);
+    default: return t_devop<Bls12_377_G2, false>(op, in, iw, out, ow, n);
+  }
+}
+
+extern "C" int ht_devop_shape(int curve, int op, int* in_words, int* out_words) {
+  if (!in_words || !out_words || curve < 0 || curve > 2) return -1;
+  devtest_shape(op, curve == 2 ? 2 * NL : NL, *in_words, *out_words);
+  if (curve != 0 && ((op >= DT_TE_MADD && op <= DT_TE_DBL) || op == DT_TE_ADD_QUAD)) *in_words = *out_words = 0;
+  return (*in_words) ? 0 : -1;
+}
