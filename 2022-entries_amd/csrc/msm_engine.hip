@@ -275,6 +275,23 @@ namespace {
 
 void ensure_device(mi355_msm_ctx* ctx) { HIP_OK(hipSetDevice(ctx->device)); }
 
+// A stream for host -> device copies that must make progress WHILE the compute stream is full of long kernels.  HIP multiplexes
+// streams onto a few hardware queues (GPU_MAX_HW_QUEUES = 4) in creation order; a copy stream that lands on the compute
+// stream's queue has its event and barrier packets stuck behind 16-ms kernels -- measured in bench.py, whose stream creation
+// order produced exactly that: the stateless pipeline ran at 26 GB/s (346 ms) instead of 54 GB/s (196 ms), and with
+// GPU_MAX_HW_QUEUES = 2 or 8 at full speed again.  Queues are pooled per priority, so a high-priority stream never shares
+// one with the (normal-priority) compute streams.
+hipStream_t create_copy_stream() {
+  hipStream_t s = nullptr;
+  int least = 0, greatest = 0;
+  if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest < least &&
+      hipStreamCreateWithPriority(&s, hipStreamNonBlocking, greatest) == hipSuccess)
+    return s;
+  (void)hipGetLastError();
+  HIP_OK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  return s;
+}
+
 // Device bytes of the per-run work buffers of one chunk (keys/vals x2, buckets, slots x2, reduce x4); `el` = 2 for Fq2 points.
 uint64_t work_bytes(const Plan& p, uint64_t el) {
   const PartPlan pp = part_plan((uint32_t)(p.entries / p.windows), p.c, p.windows, p.bucket_windows == 1 && p.windows > 1, 0, 0);
@@ -926,7 +943,7 @@ void run_host(mi355_msm_ctx* ctx, void* out, const void* scalars, size_t n, size
   const size_t bytes = n * batches * 32;
   ctx->scalars.reserve(bytes ? bytes : 32);
   if (!ctx->copy_stream) {
-    HIP_OK(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    ctx->copy_stream = create_copy_stream();
     for (auto& ev : ctx->copy_ev) HIP_OK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
   }
   HostBatches hb{(const uint8_t*)scalars, ctx->scalars.as<uint8_t>(), n * 32, host_batch_pairs * 32, ctx->copy_stream,

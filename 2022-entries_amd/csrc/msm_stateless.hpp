@@ -327,7 +327,7 @@ void stateless_t(mi355_msm_ctx* ctx, uint8_t* out, const uint8_t* affine, size_t
       lease.r = ring_acquire(ctx->device);
       up.ring = lease.r;
       tr_setup.emplace_back("ring", ms_since(t_begin));
-      HIP_OK(hipStreamCreateWithFlags(&up.copy_stream, hipStreamNonBlocking));
+      up.copy_stream = create_copy_stream();   // high priority: its own hardware queue, never behind the compute stream's kernels
       up.slice_ev.assign(S, nullptr);
       up.conv_ev.assign(S, nullptr);
       for (uint32_t s = 0; s < S; s++) {
