@@ -19,6 +19,8 @@ from .msm import (  # noqa: F401
     plan,
     msm,
     last_stateless,
+    ChunkedPippenger,
+    HashMapPippenger,
 )
 from .dist import all_gather_partials, shard_bounds, sharded_msm  # noqa: F401,E402
 from . import formats  # noqa: F401,E402

@@ -66,6 +66,10 @@ struct FpEl {
   static constexpr int WORDS = 12;
   static constexpr int ACC_WAVES = 2;   // k_accumulate: <= 256 VGPRs, two waves per SIMD saturate VALU issue
   static constexpr bool PREFETCH_BASE = true;
+#ifndef MSM_SW_ENTRY_Q
+#define MSM_SW_ENTRY_Q 2
+#endif
+  static constexpr int ENTRY_Q = MSM_SW_ENTRY_Q;   // k_accumulate_glds entry queue: half a sector per refill (155 + 8 VGPRs <= 168)
   static MSM_HD void from_abi(T& r, const uint32_t* w, const Md& md) { fe_from_abi<F>(r, w, md); }
   static MSM_HD void to_abi(uint32_t* w, const T& a, const Md& md) { fe_to_abi<F>(w, a, md); }
   static MSM_HD void reduce(T& r) { fe_reduce<F>(r); }
@@ -184,6 +188,10 @@ struct Fp2El {
 #endif
   static constexpr int ACC_WAVES = MSM_G2_ACC_WAVES;   // an Fp2 XYZZ accumulator alone is 112 VGPRs: take the whole 512-entry file
   static constexpr bool PREFETCH_BASE = false;
+#ifndef MSM_G2_ENTRY_Q
+#define MSM_G2_ENTRY_Q 0
+#endif
+  static constexpr int ENTRY_Q = MSM_G2_ENTRY_Q;   // no registers to spare (256 VGPRs + AGPRs)
   static MSM_HD void from_abi(T& r, const uint32_t* w, const Md& md) {
     fe_from_abi<F>(r.c0, w, md);
     fe_from_abi<F>(r.c1, w + 12, md);

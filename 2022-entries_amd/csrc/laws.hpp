@@ -54,6 +54,7 @@ struct SwLaw {
   static constexpr bool CHECKS = false;
   static constexpr int ACC_WAVES = E::ACC_WAVES;
   static constexpr bool PREFETCH_BASE = E::PREFETCH_BASE;
+  static constexpr int ENTRY_Q = E::ENTRY_Q;   // k_accumulate_glds: 16-byte registers of the entry queue (2 entries each); 0 = none
   static MSM_HD Base from_dev(const BaseDev& d) { return d.p; }
   static MSM_HD void set_identity(XyzzT<T>& r) { xyzz_set_inf<E>(r); }
   static MSM_HD void begin_run(XyzzT<T>&) {}   // XYZZ: the `fresh` flag makes the first madd a copy
@@ -86,8 +87,12 @@ struct TeLaw {
 #ifndef TE_PREFETCH
 #define TE_PREFETCH true
 #endif
+#ifndef TE_ENTRY_Q
+#define TE_ENTRY_Q 4
+#endif
   static constexpr int ACC_WAVES = TE_ACC_WAVES;
   static constexpr bool PREFETCH_BASE = TE_PREFETCH;
+  static constexpr int ENTRY_Q = TE_ENTRY_Q;   // a whole 64-B sector of entries per refill: 140 + 16 VGPRs, still three waves per SIMD
   static MSM_HD Base from_dev(const BaseDev& d) { return d.get(); }
   static MSM_HD void set_identity(Xyzz& r) { te_set_identity<F>(r); }
   // A run's first element is added onto the identity through the same 7M formula: a cheaper "copy" branch would be taken by

@@ -242,7 +242,7 @@ struct mi355_msm_ctx {
     // (and 4 below 2^18 entries -- a few thousand pairs -- where even 8 additions in a row are a visible share: -4 %)
     const uint64_t k_auto = std::max<uint64_t>({p.entries >= (3u << 20) ? 24u : (p.entries < (1u << 18) ? 4u : 8u), p.entries >> 20, std::min<uint64_t>(64, p.entries >> 19)});
     uint32_t K = opt_lane_entries ? (uint32_t)opt_lane_entries : (uint32_t)std::min<uint64_t>(256, k_auto);
-    p.K = (K + 3) & ~3u;
+    p.K = K >= 8 ? (K + 7) & ~7u : (K + 3) & ~3u;   // a lane's entries start on a 64-byte boundary (k_accumulate_glds refills its entry queue by whole sectors)
     p.nlanes = ceil_div(p.entries, p.K);
     p.segK = opt_seg_entries >= 4 ? (uint32_t)opt_seg_entries : (p.entries < (2u << 20) ? 4 : 8);   // small inputs: shallower levels (-1..-3 %)
     uint64_t nb = (uint64_t)p.bucket_windows * p.half;
@@ -274,6 +274,17 @@ struct mi355_msm_ctx {
 namespace {
 
 void ensure_device(mi355_msm_ctx* ctx) { HIP_OK(hipSetDevice(ctx->device)); }
+
+// Every compute entry point starts here: no device, no service (this library has no CPU fallback).  Returns the device count.
+int require_device() {
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count == 0) {
+    (void)hipGetLastError();
+    throw HipFailure((int)(e != hipSuccess ? e : hipErrorNoDevice), "mi355_msm: no HIP device visible (this library has no CPU fallback)");
+  }
+  return count;
+}
 
 // A stream for host -> device copies that must make progress WHILE the compute stream is full of long kernels.  HIP multiplexes
 // streams onto a few hardware queues (GPU_MAX_HW_QUEUES = 4) in creation order; a copy stream that lands on the compute
@@ -970,11 +981,7 @@ RustError mi355_msm_create(mi355_msm_ctx** out, int curve, int device) {
     if (!out) bad_arg("null context out-pointer");
     *out = nullptr;
     if (!known_curve(curve)) bad_arg("unknown curve id %d", curve);
-    int count = 0;
-    hipError_t e = hipGetDeviceCount(&count);
-    if (e != hipSuccess || count == 0)
-      throw HipFailure((int)(e != hipSuccess ? e : hipErrorNoDevice),
-                       "mi355_msm: no HIP device visible (this library has no CPU fallback)");
+    const int count = require_device();
     if (device < 0) HIP_OK(hipGetDevice(&device));
     if (device >= count) bad_arg("device %d out of range (%d visible)", device, count);
     HIP_OK(hipSetDevice(device));
@@ -1287,6 +1294,7 @@ RustError mi355_msm(int curve, void* out, const void* affine, size_t npoints, co
   return guarded_dev([&] {
     if (!known_curve(curve)) bad_arg("unknown curve id %d", curve);
     if (!out) bad_arg("null output pointer");
+    (void)require_device();
     // MI355_MSM_DEVICES = "0,1,2,3" | "0-7" | "all" | unset: several GPUs -> one pipeline per shard over its slice of both operands
     std::vector<int> devs{-1};
     const char* env = getenv("MI355_MSM_DEVICES");
@@ -1434,6 +1442,8 @@ RustError mi355_msm_shard_bounds(size_t npoints, int nshards, int shard, size_t*
   });
 }
 
-const char* mi355_msm_version(void) { return "mi355-msm 0.2 (gfx950)"; }
+const char* mi355_msm_version(void) { return "mi355-msm 0.3 (gfx950)"; }
 
 }  // extern "C"
+
+#include "msm_stream.hpp"

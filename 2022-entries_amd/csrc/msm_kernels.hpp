@@ -172,7 +172,10 @@ __global__ void __launch_bounds__(256, G::ACC_WAVES) k_accumulate_glds(const uin
   using Base = typename G::Base;
   constexpr int SECT = sizeof(typename G::BaseDev) / 64;   // 64-B sectors per record
   constexpr int RS = 1024;                                 // bytes of one (record index, sector) region: 64 lanes x 16 B
-  constexpr int WAVE_LDS = 4 * SECT * RS + 256;
+#ifndef MSM_ACC_LDS_PAD
+#define MSM_ACC_LDS_PAD 0   // A/B only: extra LDS per wave lowers the number of resident blocks (profiles/r03_ab_occupancy.txt)
+#endif
+  constexpr int WAVE_LDS = 4 * SECT * RS + 256 + MSM_ACC_LDS_PAD;
   static_assert(sizeof(typename G::BaseDev) % 64 == 0 && SECT >= 2 && SECT <= 4, "record layout");
   __shared__ __attribute__((aligned(16))) unsigned char lds[4 * WAVE_LDS];
   const uint32_t t = blockIdx.x * 256 + threadIdx.x;
@@ -193,8 +196,46 @@ __global__ void __launch_bounds__(256, G::ACC_WAVES) k_accumulate_glds(const uin
   const uint32_t beg = has_work ? (uint32_t)beg64 : 0;
   const uint32_t end = has_work ? ((n_entries - beg > K) ? beg + K : n_entries) : 0;
 
+  // The sorted entries of a lane are consecutive in memory, but the lanes of a wave are K entries (2 KB) apart: an 8-byte
+  // load per lane and iteration touches 64 different 64-B sectors, and by the next iteration -- 4.7 MB of base records per XCD
+  // later -- the sector has left the 4-MB L2, so every entry cost a whole sector: 56 GB of the 167 GB the counters report for
+  // the 2^26 launch (profiles/r03_calib_fetch.txt + r03_pmc_k_accumulate.json) against 7 GB of entries.  With EQ > 0 a lane
+  // fetches 2 EQ entries at once (EQ 16-byte loads issued back to back: one request for a whole sector when EQ = 4) into a
+  // register queue, refilled every 2 EQ iterations; entries are popped by a static rotation (no dynamic register indexing).
+  constexpr int EQ = G::ENTRY_Q;
+  uint4 q[EQ > 0 ? EQ : 1];
+  uint32_t q_left = 0;   // wave-uniform
+#define MSM_Q_REFILL(first_entry)                                                   \
+  do {                                                                              \
+    const uint4* src_ = reinterpret_cast<const uint4*>(entries + (first_entry));    \
+    _Pragma("unroll") for (int j_ = 0; j_ < EQ; j_++) q[j_] = src_[j_];             \
+  } while (0)
+#define MSM_Q_POP(key_out, val_out)                                                 \
+  do {                                                                              \
+    key_out = q[0].y;                                                               \
+    val_out = q[0].x;                                                               \
+    _Pragma("unroll") for (int j_ = 0; j_ < EQ; j_++) {                             \
+      q[j_].x = q[j_].z;                                                            \
+      q[j_].y = q[j_].w;                                                            \
+      if (j_ + 1 < EQ) {                                                            \
+        q[j_].z = q[j_ + 1].x;                                                      \
+        q[j_].w = q[j_ + 1].y;                                                      \
+      }                                                                             \
+    }                                                                               \
+  } while (0)
   uint32_t key_c = KEY_NONE, val_c = 0, key_n = KEY_NONE, val_n = 0;
-  if (end > beg) {
+  if constexpr (EQ > 0) {
+    // (entries past a lane's `end` belong to the next lane, or to the 64 bytes of slack behind the buffer; they are never used)
+    if (end > beg) MSM_Q_REFILL(beg);
+    MSM_Q_POP(key_c, val_c);
+    MSM_Q_POP(key_n, val_n);
+    q_left = 2 * EQ - 2;
+    if (q_left == 0) {
+      if (end - beg > 2 && end > beg) MSM_Q_REFILL(beg + 2);
+      q_left = 2 * EQ;
+    }
+    if (end <= beg) key_c = key_n = KEY_NONE;
+  } else if (end > beg) {
     const uint2 e0 = entries[beg];
     key_c = e0.y;
     val_c = e0.x;
@@ -240,7 +281,15 @@ __global__ void __launch_bounds__(256, G::ACC_WAVES) k_accumulate_glds(const uin
     val_c = val_n;
     alive = add_now && (end - e > 1);
     MSM_GLDS_ISSUE(val_c, alive);
-    if (add_now && end - e > 2) {
+    if constexpr (EQ > 0) {
+      MSM_Q_POP(key_n, val_n);   // entry e + 2
+      // the pop that empties the queue starts the refill: the loads are in flight during this iteration's addition and are
+      // covered by the s_waitcnt vmcnt(0) at the top of the next one (q_left is wave-uniform: every lane pops once per iteration)
+      if (--q_left == 0) {
+        if (add_now && end - e > 3) MSM_Q_REFILL(e + 3);
+        q_left = 2 * EQ;
+      }
+    } else if (add_now && end - e > 2) {
       const uint2 e2 = entries[e + 2];
       key_n = e2.y;
       val_n = e2.x;
@@ -268,6 +317,8 @@ __global__ void __launch_bounds__(256, G::ACC_WAVES) k_accumulate_glds(const uin
   if (G::CHECKS && bad) flags[1] = 1;
 #undef MSM_GLDS_ISSUE
 #undef MSM_GLDS_ONE
+#undef MSM_Q_REFILL
+#undef MSM_Q_POP
 }
 
 // Merge run fragments: same walk over the slot sequence of the previous level (keys non-decreasing,

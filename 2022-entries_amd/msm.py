@@ -99,6 +99,12 @@ def load_library() -> ctypes.CDLL:
         "mi355_msm_set_bases_serialized": [vp, vp, sz],
         "mi355_msm_point_to_serialized": [ci, vp, vp],
         "mi355_msm_last_stateless": [ctypes.POINTER(ctypes.c_double), sz],
+        "mi355_msm_stream_create": [ctypes.POINTER(vp), ci, ci, sz, ci],
+        "mi355_msm_stream_set_option": [vp, ctypes.c_char_p, ctypes.c_long],
+        "mi355_msm_stream_add": [vp, vp, sz, vp, sz],
+        "mi355_msm_stream_finalize": [vp, vp],
+        "mi355_msm_stream_query": [vp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_uint64)],
+        "mi355_msm_stream_destroy": [vp],
         "mi355_msm_trim": [],
     }
     for name, args in sigs.items():
@@ -387,6 +393,64 @@ class VariableBaseMSM:
             return fold_partials(partials, self.curve)
         finally:
             ctx.close()
+
+
+class ChunkedPippenger:
+    """``ChunkedPippenger::{new, with_size, add, finalize}`` (ARK ec/src/msm/variable_base/stream_pippenger.rs:11-75): buffer
+    (base, BigInt scalar) pairs; every ``buf_size`` pairs ``result += msm_bigint(buffer)``; ``finalize`` flushes the rest.
+    ``add`` takes one pair or arrays of pairs (byte images as everywhere in this module)."""
+
+    _HASHMAP = 0
+
+    def __init__(self, max_msm_buffer: int, curve="bls12_377_g1", device: Optional[int] = None):
+        self.curve = _curve_id(curve)
+        self._lib = load_library()
+        self.stream = ctypes.c_void_p()
+        _check(self._lib.mi355_msm_stream_create(ctypes.byref(self.stream), self.curve, -1 if device is None else device,
+                                                 max_msm_buffer, self._HASHMAP))
+
+    new = classmethod(lambda cls, max_msm_buffer, curve="bls12_377_g1": cls(max_msm_buffer, curve))
+    with_size = new
+
+    def set_option(self, key: str, value: int) -> None:
+        _check(self._lib.mi355_msm_stream_set_option(self.stream, key.encode(), int(value)))
+
+    def add(self, bases, scalars, stride: Optional[int] = None) -> None:
+        stride = affine_stride(self.curve) if stride is None else stride
+        b, s = _Buf(bases), _Buf(scalars)
+        if b.is_device or s.is_device:
+            raise TypeError("the streaming accumulators buffer pairs on the host: pass host arrays")
+        if b.nbytes % stride or s.nbytes % SCALAR_BYTES or b.nbytes // stride != s.nbytes // SCALAR_BYTES:
+            raise ValueError("bases and scalars must hold the same number of pairs")
+        _check(self._lib.mi355_msm_stream_add(self.stream, b.ptr, stride, s.ptr, s.nbytes // SCALAR_BYTES))
+
+    def finalize(self) -> bytes:
+        out = ctypes.create_string_buffer(projective_bytes(self.curve))
+        _check(self._lib.mi355_msm_stream_finalize(self.stream, out))
+        return out.raw
+
+    def query(self, key: str) -> int:
+        v = ctypes.c_uint64(0)
+        _check(self._lib.mi355_msm_stream_query(self.stream, key.encode(), ctypes.byref(v)))
+        return int(v.value)
+
+    def close(self) -> None:
+        if self.stream:
+            _check(self._lib.mi355_msm_stream_destroy(self.stream))
+            self.stream = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class HashMapPippenger(ChunkedPippenger):
+    """``HashMapPippenger::{new, add, finalize}`` (stream_pippenger.rs:78-140): a pair whose base is already buffered adds its
+    scalar (an ``Fr`` value) to that entry modulo r; the MSM runs when ``max_msm_buffer`` DISTINCT bases are buffered."""
+
+    _HASHMAP = 1
 
 
 def fold_partials(partials: Sequence[bytes], curve="bls12_377_g1") -> bytes:

@@ -170,6 +170,24 @@ RustError mi355_msm(int curve, void* out_projective, const void* affine, size_t 
 RustError mi355_msm_last_stateless(double* out, size_t count);
 RustError mi355_msm_trim(void);
 
+/* ---- arkworks' streaming accumulators (ARK ec/src/msm/variable_base/stream_pippenger.rs) ---------------------------------
+ * ChunkedPippenger::{new, with_size, add, finalize} (:11-75) and HashMapPippenger::{new, add, finalize} (:78-140): what a prover
+ * holds across rounds.  `hashmap` = 0: buffer pairs, and whenever the buffer holds max_msm_buffer of them, result += MSM(buffer).
+ * `hashmap` = 1: a pair whose base (x, y, infinity flag) is already buffered adds its scalar to that entry modulo the scalar
+ * field order r -- scalars are Fr values there -- and the MSM runs when max_msm_buffer DISTINCT bases are buffered.
+ * add() takes `count` pairs (bases `stride` bytes apart) and behaves exactly like `count` single adds.  finalize() flushes what
+ * is left, writes the normalised Projective image and leaves the accumulator empty for reuse (arkworks' finalize consumes it).
+ * Each flush is the stateless pipeline of mi355_msm() on `device` (< 0: the current device).  Options: "scalars_montgomery"
+ * (the scalars are arkworks Fr images, converted on the device -- sums of Montgomery images are Montgomery images of sums),
+ * "window_bits".  Queries: "buffered", "flushes", "merged" (pairs that landed on an existing hashmap entry), "buf_size". */
+typedef struct mi355_msm_stream mi355_msm_stream;
+RustError mi355_msm_stream_create(mi355_msm_stream** out, int curve, int device, size_t max_msm_buffer, int hashmap);
+RustError mi355_msm_stream_set_option(mi355_msm_stream* s, const char* key, long value);
+RustError mi355_msm_stream_add(mi355_msm_stream* s, const void* affine, size_t stride, const void* scalars, size_t count);
+RustError mi355_msm_stream_finalize(mi355_msm_stream* s, void* out_projective);
+RustError mi355_msm_stream_query(mi355_msm_stream* s, const char* key, uint64_t* value);
+RustError mi355_msm_stream_destroy(mi355_msm_stream* s);
+
 /* Sum `count` projective images (any Z) into one normalised image: the multi-GPU combine step
  * ("final 8-point curve add").  Pure host arithmetic on <= a few dozen points; no device needed. */
 RustError mi355_msm_fold(int curve, void* out_projective, const void* projective, size_t count);

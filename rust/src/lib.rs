@@ -114,6 +114,16 @@ pub mod sys {
         pub fn mi355_msm(curve: c_int, out_projective: *mut c_void, affine: *const c_void, npoints: usize, scalars: *const c_void, ffi_affine_sz: usize) -> Error;
         pub fn mi355_msm_fold(curve: c_int, out_projective: *mut c_void, projective: *const c_void, count: usize) -> Error;
         pub fn mi355_msm_point_to_serialized(curve: c_int, projective: *const c_void, out_record: *mut c_void) -> Error;
+        pub fn mi355_msm_shard_timings(ctx: *mut c_void, shard: c_int, ms: *mut f32, info: *mut u64) -> Error;
+        pub fn mi355_msm_last_stateless(out: *mut f64, count: usize) -> Error;
+        pub fn mi355_msm_trim() -> Error;
+        // arkworks' streaming accumulators (ark-ec stream_pippenger.rs) over the engine
+        pub fn mi355_msm_stream_create(out: *mut *mut c_void, curve: c_int, device: c_int, max_msm_buffer: usize, hashmap: c_int) -> Error;
+        pub fn mi355_msm_stream_set_option(s: *mut c_void, key: *const c_char, value: c_long) -> Error;
+        pub fn mi355_msm_stream_add(s: *mut c_void, affine: *const c_void, stride: usize, scalars: *const c_void, count: usize) -> Error;
+        pub fn mi355_msm_stream_finalize(s: *mut c_void, out_projective: *mut c_void) -> Error;
+        pub fn mi355_msm_stream_query(s: *mut c_void, key: *const c_char, value: *mut u64) -> Error;
+        pub fn mi355_msm_stream_destroy(s: *mut c_void) -> Error;
     }
 }
 
@@ -202,9 +212,19 @@ pub mod variable_base {
     }
 
     /// `VariableBaseMSM::msm_bigint`: chops to the shorter slice (ARK ec/src/msm/variable_base/mod.rs:68-76).
+    /// Both operands are in host memory and used once: the stateless entry point, whose upload is pipelined with the compute
+    /// (slices of bases and scalars cross PCIe while earlier slices are converted and run).
     pub fn msm_bigint(bases: &[G1Affine], bigints: &[<Fr as PrimeField>::BigInt]) -> G1Projective {
         let n = bases.len().min(bigints.len());
-        run(bases, bigints.as_ptr() as *const c_void, n, false)
+        let mut out = G1Projective::zero();
+        let err = unsafe {
+            sys::mi355_msm(CURVE, &mut out as *mut _ as *mut c_void, bases.as_ptr() as *const c_void, n, bigints.as_ptr() as *const c_void,
+                           std::mem::size_of::<G1Affine>())
+        };
+        if err.code != 0 {
+            panic!("{}", String::from(err));
+        }
+        out
     }
 
     /// `VariableBaseMSM::msm` on field elements (ARK ec/src/msm/variable_base/mod.rs:48-53).
@@ -218,5 +238,128 @@ pub mod variable_base {
         (bases.len() == scalars.len())
             .then(|| msm(bases, scalars))
             .ok_or(usize::min(bases.len(), scalars.len()))
+    }
+}
+
+/// arkworks' streaming accumulators (ark-ec `msm::variable_base::stream_pippenger`): `ChunkedPippenger::{new, with_size, add,
+/// finalize}` and `HashMapPippenger::{new, add, finalize}` with the reference's names and meaning; every flush is one
+/// pipelined MSM on the GPU.
+pub mod stream_pippenger {
+    use super::sys;
+    use super::{Fr, G1Affine};
+    use ark_ec::AffineCurve;
+    use ark_ff::PrimeField;
+    use ark_std::Zero;
+    use std::borrow::Borrow;
+    use std::os::raw::{c_char, c_int, c_void};
+
+    type G1Projective = <G1Affine as AffineCurve>::Projective;
+
+    #[cfg(not(feature = "bls12_381"))]
+    const CURVE: c_int = sys::MI355_BLS12_377_G1;
+    #[cfg(feature = "bls12_381")]
+    const CURVE: c_int = sys::MI355_BLS12_381_G1;
+
+    fn check(err: super::Error) {
+        if err.code != 0 {
+            panic!("{}", String::from(err));
+        }
+    }
+
+    fn create(buf_size: usize, hashmap: c_int) -> *mut c_void {
+        let mut s: *mut c_void = std::ptr::null_mut();
+        check(unsafe { sys::mi355_msm_stream_create(&mut s, CURVE, -1, buf_size, hashmap) });
+        s
+    }
+
+    fn finalize(stream: *mut c_void) -> G1Projective {
+        let mut out = G1Projective::zero();
+        check(unsafe { sys::mi355_msm_stream_finalize(stream, &mut out as *mut _ as *mut c_void) });
+        check(unsafe { sys::mi355_msm_stream_destroy(stream) });
+        out
+    }
+
+    /// Struct for the chunked Pippenger algorithm.
+    pub struct ChunkedPippenger {
+        stream: *mut c_void,
+    }
+
+    impl ChunkedPippenger {
+        /// Initialize a chunked Pippenger instance with default parameters.
+        pub fn new(max_msm_buffer: usize) -> Self {
+            Self { stream: create(max_msm_buffer, 0) }
+        }
+
+        /// Initialize a chunked Pippenger instance with the given buffer size.
+        pub fn with_size(buf_size: usize) -> Self {
+            Self { stream: create(buf_size, 0) }
+        }
+
+        /// Add a new (base, scalar) pair into the instance.
+        pub fn add<B, S>(&mut self, base: B, scalar: S)
+        where
+            B: Borrow<G1Affine>,
+            S: Borrow<<Fr as PrimeField>::BigInt>,
+        {
+            check(unsafe {
+                sys::mi355_msm_stream_add(
+                    self.stream,
+                    base.borrow() as *const G1Affine as *const c_void,
+                    std::mem::size_of::<G1Affine>(),
+                    scalar.borrow() as *const _ as *const c_void,
+                    1,
+                )
+            });
+        }
+
+        /// Add a slice of pairs at once (same result as adding them one by one).
+        pub fn add_slice(&mut self, bases: &[G1Affine], scalars: &[<Fr as PrimeField>::BigInt]) {
+            let n = bases.len().min(scalars.len());
+            check(unsafe {
+                sys::mi355_msm_stream_add(self.stream, bases.as_ptr() as *const c_void, std::mem::size_of::<G1Affine>(), scalars.as_ptr() as *const c_void, n)
+            });
+        }
+
+        /// Output the final Pippenger algorithm result.
+        pub fn finalize(self) -> G1Projective {
+            finalize(self.stream)
+        }
+    }
+
+    /// Hash map struct for Pippenger algorithm.
+    pub struct HashMapPippenger {
+        stream: *mut c_void,
+    }
+
+    impl HashMapPippenger {
+        /// Produce a new hash map with the maximum msm buffer size.
+        pub fn new(max_msm_buffer: usize) -> Self {
+            let stream = create(max_msm_buffer, 1);
+            // the scalars of this accumulator are `Fr` values (Montgomery images): the device converts at the flush
+            check(unsafe { sys::mi355_msm_stream_set_option(stream, b"scalars_montgomery\0".as_ptr() as *const c_char, 1) });
+            Self { stream }
+        }
+
+        /// Add a new (base, scalar) pair into the hash map.
+        pub fn add<B, S>(&mut self, base: B, scalar: S)
+        where
+            B: Borrow<G1Affine>,
+            S: Borrow<Fr>,
+        {
+            check(unsafe {
+                sys::mi355_msm_stream_add(
+                    self.stream,
+                    base.borrow() as *const G1Affine as *const c_void,
+                    std::mem::size_of::<G1Affine>(),
+                    scalar.borrow() as *const Fr as *const c_void,
+                    1,
+                )
+            });
+        }
+
+        /// Update the final result with (base, scalar) pairs in the hash map.
+        pub fn finalize(self) -> G1Projective {
+            finalize(self.stream)
+        }
     }
 }

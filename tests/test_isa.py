@@ -61,6 +61,10 @@ def test_accumulate_kernel_isa(law):
     # the gathers are LDS-DMA (global -> LDS, no VGPR staging, no ds_write): 4 records x SECT sectors per addition
     sect = 2 if law == "sw" else 3
     assert ops.count("global_load_lds_dwordx4") == 2 * 4 * sect and ops.count("ds_write_b128") == 0
+    # the sorted entries arrive through a register queue refilled by back-to-back 16-byte loads (a whole 64-B sector for the
+    # twisted-Edwards kernel, half a sector for XYZZ): no 8-byte entry load per iteration is left
+    eq = 4 if law == "te" else 2
+    assert ops.count("global_load_dwordx2") == 0 and ops.count("global_load_dwordx4") >= 2 * eq, (ops.count("global_load_dwordx2"), ops.count("global_load_dwordx4"))
     if law == "te":
         # Y - X and Y + X are read from each other's sector for a negated base: per-lane LDS addresses, 14 selects left (2dXY)
         assert ops.count("v_cndmask_b32_e64") <= 24 and res["vgprs"] <= 168      # 3 waves/SIMD resident
@@ -68,7 +72,7 @@ def test_accumulate_kernel_isa(law):
         # MSM_MONT_STEP) -- 14 per multiplication, 7 multiplications; the rest of the VALU stream is bounded below
         assert ops.count("v_bfi_b32") == 98, ops.count("v_bfi_b32")
         valu = [o for o in ops if o.startswith("v_")]
-        assert len(valu) - mads <= 960, len(valu) - mads     # whole kernel (static count), prologue and flushes included
+        assert len(valu) - mads <= 1000, len(valu) - mads    # whole kernel (static count), prologue, flushes and the queue rotation (14 moves) included
     else:
         # the common path of the mixed addition keeps neither base coordinate alive (curve.hpp xyzz_madd_common): 3 waves/SIMD
         assert res["vgprs"] <= 168, res["vgprs"]
