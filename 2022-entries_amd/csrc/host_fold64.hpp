@@ -46,6 +46,11 @@ struct F64 {
   "mulxq 40(%[p]), %%rax, %%rbx\n\t adcxq %%rax, %%" #t5 "\n\t adoxq %%rbx, %%" #t6 "\n\t"            \
   "adcxq %[zero], %%" #t6 "\n\t"
 
+// (under AddressSanitizer locals live on a fake stack addressed through one more register than this block can spare -- it
+//  clobbers ten and takes four pointers: the function itself is left uninstrumented there, its callers are not)
+#if defined(__SANITIZE_ADDRESS__)
+__attribute__((no_sanitize_address, noinline))
+#endif
 inline void mont_mul_adx(uint64_t* out, const uint64_t* a, const uint64_t* b, const uint64_t* p, uint64_t inv) {
   static const uint64_t zero = 0;
   asm volatile(

@@ -27,16 +27,15 @@
 #include "../../include/mi355_msm.h"
 #include "host_curve.hpp"
 #include "host_fold64.hpp"
+#include "host_pipeline.hpp"
 #include "launch.hpp"
 
 namespace {
 
 using namespace msm;
 
-struct HipFailure : std::runtime_error {
-  int code;
-  HipFailure(int c, const std::string& m) : std::runtime_error(m), code(c) {}
-};
+// (the HIP-free host concurrency of host_pipeline.hpp throws PipelineError; a HIP failure IS one, so one handler serves both)
+using HipFailure = msm_host::PipelineError;
 
 #define HIP_OK(expr)                                                                                   \
   do {                                                                                                 \

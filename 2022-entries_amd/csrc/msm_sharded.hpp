@@ -129,40 +129,14 @@ static void take(RustError e) {
   throw HipFailure(e.code, m);
 }
 
-// Run fn(g) for every shard on its own host thread; rethrow the first failure with the shard named.
+// Run fn(g) for every shard on its own host thread; rethrow the first failure with the shard named (host_pipeline.hpp).
 template <class Fn>
 static void for_each_shard(mi355_msm_ctx* ctx, Fn&& fn) {
-  const size_t G = ctx->shards.size();
-  std::vector<std::string> errors(G);
-  std::vector<int> codes(G, 0);
-  auto body = [&](size_t g) {
-    try {
-      fn(g);
-    } catch (const HipFailure& e) {
-      codes[g] = e.code ? e.code : -1;
-      errors[g] = e.what();
-    } catch (const std::exception& e) {
-      codes[g] = -1;
-      errors[g] = e.what();
-    } catch (...) {
-      codes[g] = -1;
-      errors[g] = "unknown C++ exception";
-    }
-  };
-  if (G == 1) {
-    body(0);
-  } else {
-    std::vector<std::thread> threads;
-    threads.reserve(G);
-    for (size_t g = 0; g < G; g++) threads.emplace_back(body, g);
-    for (auto& t : threads) t.join();
-  }
-  for (size_t g = 0; g < G; g++)
-    if (codes[g]) {
-      char buf[640];
-      snprintf(buf, sizeof buf, "shard %zu (device %d): %s", g, ctx->shards[g]->device, errors[g].c_str());
-      throw HipFailure(codes[g], buf);
-    }
+  msm_host::run_on_shards(ctx->shards.size(), fn, [&](size_t g) {
+    char buf[64];
+    snprintf(buf, sizeof buf, "shard %zu (device %d)", g, ctx->shards[g]->device);
+    return std::string(buf);
+  });
 }
 
 static void sharded_destroy(mi355_msm_ctx* ctx) {

@@ -32,8 +32,8 @@
 namespace {
 
 struct StageRing {
-  static constexpr int SLOTS = 12;
-  static constexpr size_t PIECE = (size_t)16 << 20;
+  static constexpr int SLOTS = msm_host::RING_SLOTS;
+  static constexpr size_t PIECE = msm_host::RING_PIECE;
   int device = -1;
   void* slot[SLOTS] = {};
   hipEvent_t ev[SLOTS] = {};
@@ -134,105 +134,24 @@ long env_long(const char* name, long dflt, long lo, long hi) {
   return v;
 }
 
-struct Piece {
-  const uint8_t* src;
-  uint8_t* dst;
-  size_t bytes;
-  uint32_t slice;
-  bool raw;   // lands in the ring of raw-record buffers (bases) rather than in the scalar buffer
+// The device calls of the staging pipeline (host_pipeline.hpp UploaderT<Api>).
+struct HipPipelineApi {
+  using stream_t = hipStream_t;
+  using event_t = hipEvent_t;
+  static void set_device(int d) { HIP_OK(hipSetDevice(d)); }
+  static void event_sync(hipEvent_t e) { HIP_OK(hipEventSynchronize(e)); }
+  static void stream_wait(hipStream_t s, hipEvent_t e) { HIP_OK(hipStreamWaitEvent(s, e, 0)); }
+  static void copy_h2d(void* dst, const void* src, size_t bytes, hipStream_t s) { HIP_OK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s)); }
+  static void event_record(hipEvent_t e, hipStream_t s) { HIP_OK(hipEventRecord(e, s)); }
 };
+using msm_host::Piece;
 
-// The upload side of one stateless call: staging threads, the copy stream, one event per slice.
-struct Uploader {
-  mi355_msm_ctx* ctx;
-  StageRing* ring;
-  hipStream_t copy_stream;
-  std::vector<Piece> pieces;
-  std::vector<hipEvent_t> slice_ev, conv_ev;
-  std::unique_ptr<std::atomic<int>[]> slice_left, slice_ready, conv_recorded;
-  std::atomic<size_t> next{0};
-  std::atomic<size_t> slot_gen[StageRing::SLOTS];
-  std::atomic<int> failed{0};
-  std::mutex err_mu;
-  std::string err;
-  int err_code = 0;
-  uint32_t raw_ring = 3;   // device buffers for raw base records: slice s uses buffer s % raw_ring
-  std::vector<std::thread> threads;
-
-  void fail(int code, const std::string& what) {
-    std::lock_guard<std::mutex> lk(err_mu);
-    if (!failed.exchange(1)) {
-      err_code = code ? code : -1;
-      err = what;
-    }
-  }
-
-  void worker() {
-    try {
-      HIP_OK(hipSetDevice(ctx->device));
-      for (;;) {
-        const size_t k = next.fetch_add(1);
-        if (k >= pieces.size() || failed.load()) return;
-        const Piece& pc = pieces[k];
-        const int slot = (int)(k % StageRing::SLOTS);
-        const size_t gen = k / StageRing::SLOTS;
-        // the slot's previous piece must have been enqueued (its thread claimed it earlier and depends on nothing later) ...
-        while (slot_gen[slot].load(std::memory_order_acquire) != gen) {
-          if (failed.load()) return;
-          std::this_thread::yield();
-        }
-        if (gen) HIP_OK(hipEventSynchronize(ring->ev[slot]));   // ... and its DMA must have left the slot
-        memcpy(ring->slot[slot], pc.src, pc.bytes);
-        // the raw-record buffer of slice s held slice s - raw_ring before: that slice's conversion must be ahead of this DMA
-        if (pc.raw && pc.slice >= raw_ring) {
-          const uint32_t dep = pc.slice - raw_ring;
-          while (!conv_recorded[dep].load(std::memory_order_acquire)) {
-            if (failed.load()) return;
-            std::this_thread::yield();
-          }
-          HIP_OK(hipStreamWaitEvent(copy_stream, conv_ev[dep], 0));
-        }
-        HIP_OK(hipMemcpyAsync(pc.dst, ring->slot[slot], pc.bytes, hipMemcpyHostToDevice, copy_stream));
-        HIP_OK(hipEventRecord(ring->ev[slot], copy_stream));
-        slot_gen[slot].store(gen + 1, std::memory_order_release);
-        // every copy of the slice is enqueued before its counter reaches zero, so the event covers them all
-        if (slice_left[pc.slice].fetch_sub(1) == 1) {
-          HIP_OK(hipEventRecord(slice_ev[pc.slice], copy_stream));
-          slice_ready[pc.slice].store(1, std::memory_order_release);
-        }
-      }
-    } catch (const HipFailure& e) {
-      fail(e.code, e.what());
-    } catch (const std::exception& e) {
-      fail(-1, e.what());
-    }
-  }
-
-  // Block until slice s is fully enqueued, then make `st` wait for its DMAs.
-  void await_slice(uint32_t s, hipStream_t st) {
-    while (!slice_ready[s].load(std::memory_order_acquire)) {
-      if (failed.load()) throw_failure();
-      std::this_thread::yield();
-    }
-    HIP_OK(hipStreamWaitEvent(st, slice_ev[s], 0));
-  }
-
-  [[noreturn]] void throw_failure() {
-    std::lock_guard<std::mutex> lk(err_mu);
-    throw HipFailure(err_code ? err_code : -1, "stateless upload: " + err);
-  }
-
-  void join() {
-    for (auto& t : threads)
-      if (t.joinable()) t.join();
-    threads.clear();
-  }
-
+// The upload side of one stateless call: the staging threads of UploaderT plus the HIP objects it drives.
+struct Uploader : msm_host::UploaderT<HipPipelineApi> {
   ~Uploader() {
-    failed.store(1);   // a compute-side failure: let the staging threads drain
-    join();
+    abort_and_join();   // a compute-side failure: let the staging threads drain
     if (copy_stream) {
-      (void)hipStreamSynchronize(copy_stream);   // DMAs out of the ring may still be in flight: the ring goes back to the pool next
+      (void)hipStreamSynchronize(copy_stream);   // copies out of the ring may still be in flight: the ring goes back to the pool next
       (void)hipStreamDestroy(copy_stream);
     }
     for (auto e : slice_ev)
@@ -289,7 +208,7 @@ void stateless_t(mi355_msm_ctx* ctx, uint8_t* out, const uint8_t* affine, size_t
     std::vector<std::pair<const char*, double>> tr_setup;
     hipEvent_t tr_t0 = nullptr;
     Uploader up;
-    up.ctx = ctx;
+    up.device = ctx->device;
     up.copy_stream = nullptr;
     up.raw_ring = std::min<uint32_t>(3, S);
     DevBuf* raw = ctx->stateless_raw;
@@ -325,7 +244,8 @@ void stateless_t(mi355_msm_ctx* ctx, uint8_t* out, const uint8_t* affine, size_t
       }
       tr_setup.emplace_back("bases + scalars + work buffers", ms_since(t_begin));
       lease.r = ring_acquire(ctx->device);
-      up.ring = lease.r;
+      up.ring_slot = lease.r->slot;
+      up.ring_ev = lease.r->ev;
       tr_setup.emplace_back("ring", ms_since(t_begin));
       up.copy_stream = create_copy_stream();   // high priority: its own hardware queue, never behind the compute stream's kernels
       up.slice_ev.assign(S, nullptr);
@@ -339,10 +259,7 @@ void stateless_t(mi355_msm_ctx* ctx, uint8_t* out, const uint8_t* affine, size_t
         HIP_OK(hipEventRecord(tr_t0, up.copy_stream));
       }
       tr_setup.emplace_back("stream + events", ms_since(t_begin));
-      up.slice_left.reset(new std::atomic<int>[S]);
-      up.slice_ready.reset(new std::atomic<int>[S]);
-      up.conv_recorded.reset(new std::atomic<int>[S]);
-      for (auto& g : up.slot_gen) g.store(0);
+      up.prepare(S);
       // pieces in upload order: the scalars of a slice first (its grouping needs them before the accumulation needs bases)
       for (uint32_t s = 0; s < S; s++) {
         const size_t cnt = lo[s + 1] - lo[s];
@@ -356,15 +273,13 @@ void stateless_t(mi355_msm_ctx* ctx, uint8_t* out, const uint8_t* affine, size_t
         cut(scalars + lo[s] * 32, ctx->scalars.as<uint8_t>() + lo[s] * 32, cnt * 32, false);
         cut(affine + lo[s] * stride, raw[s % up.raw_ring].as<uint8_t>(), cnt * stride, true);
         up.slice_left[s].store(count);
-        up.slice_ready[s].store(0);
-        up.conv_recorded[s].store(0);
       }
       const long want = env_long("MI355_MSM_STAGE_THREADS", 6, 1, StageRing::SLOTS);
       const size_t T = std::min<size_t>((size_t)want, up.pieces.size());
       stats.threads = (double)T;
       stats.slices = S;
       stats.bytes = (double)(n * (stride + 32));
-      for (size_t t = 0; t < T; t++) up.threads.emplace_back([&up] { up.worker(); });
+      up.start(T);
       stats.setup_ms = ms_since(t_begin);
 
       for (uint32_t s = 0; s < S; s++) {
@@ -376,7 +291,7 @@ void stateless_t(mi355_msm_ctx* ctx, uint8_t* out, const uint8_t* affine, size_t
         const auto t_comp = std::chrono::steady_clock::now();
         HIP_OK(Launch<E>::convert_bases(raw[s % up.raw_ring].as<uint8_t>(), stride, (uint32_t)cnt, false, ctx->bases.as<AD>(), ctx->inf.as<uint8_t>(), st));
         HIP_OK(hipEventRecord(up.conv_ev[s], st));
-        up.conv_recorded[s].store(1, std::memory_order_release);
+        up.conversion_recorded(s);
         ctx->nbases = cnt;
         // the slice as chunks of the ordinary pipeline (one, unless device memory is short)
         size_t max_chunk = ctx->opt_max_chunk ? (size_t)ctx->opt_max_chunk : ((size_t)1 << 26);
@@ -420,8 +335,7 @@ void stateless_t(mi355_msm_ctx* ctx, uint8_t* out, const uint8_t* affine, size_t
         (void)hipEventDestroy(tr_t0);
       }
     } catch (...) {
-      up.failed.store(1);
-      up.join();
+      up.abort_and_join();
       (void)hipStreamSynchronize(st);
       if (up.copy_stream) (void)hipStreamSynchronize(up.copy_stream);
       throw;

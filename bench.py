@@ -57,16 +57,19 @@ def uniform_scalars(n, top_limb, device, seed):
 
 
 def kernel_source_sha16():
-    """Identity of the kernel sources this library was built from (csrc/*): PMC figures measured on another version of the
+    """Identity of the kernel sources this library was built from: PMC figures measured on another version of the
     kernels are not quoted as if they belonged to this one."""
-    import glob
     import hashlib
 
     h = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(ROOT, "2022-entries_amd", "csrc", "*"))):
-        if os.path.isfile(f):
-            h.update(os.path.basename(f).encode())
-            h.update(open(f, "rb").read())
+    # what the accumulate kernels are compiled from (field, group laws, kernels, launchers); host-only files -- the engine, the
+    # fold, the staging pipeline, test scaffolding -- can change without invalidating a counter measurement
+    kernel_files = ("curve.hpp", "digits.hpp", "field_consts.inc", "fp28.hpp", "laws.hpp", "launch.hpp", "launch_impl.hpp", "msm_kernels.hpp",
+                    "msm_types.hpp", "te.hpp", "kernels_377g1.hip", "kernels_377g2.hip", "kernels_377te.hip", "kernels_381g1.hip")
+    for name in kernel_files:
+        f = os.path.join(ROOT, "2022-entries_amd", "csrc", name)
+        h.update(name.encode())
+        h.update(open(f, "rb").read())
     return h.hexdigest()[:16]
 
 
@@ -277,15 +280,20 @@ def main():
         # profiles/); they are only quoted for the configuration they were measured on
         # They are NOT measured by this run (counters need their own rocprofv3 pass): `traffic_from` says where the figure was
         # measured, and it is only quoted when that pass ran on the very kernel sources this library was built from.
-        traffic, traffic_from, valu = None, None, None
-        pmc_rel = os.path.join("profiles", "r02_pmc_k_accumulate.json")
+        traffic, traffic_raw, traffic_from, valu = None, None, None, None
+        pmc_rel = os.path.join("profiles", "r03_pmc_k_accumulate%s.json" % {0: "", 1: "_381", 2: "_g2"}[cid])
         pmc_path = os.path.join(ROOT, pmc_rel)
-        if cid == 0 and args.npow == 26 and not args.window_bits and not args.lane_entries and not args.precompute and os.path.exists(pmc_path):
+        if (args.npow == (24 if cid == 2 else 26) and not total_npow and not args.window_bits and not args.lane_entries and not args.precompute
+                and os.path.exists(pmc_path)):
             pmc = json.load(open(pmc_path))
             sha = kernel_source_sha16()
             if pmc.get("kernel_source_sha16") == sha:
-                traffic = pmc["traffic_bytes_raw"]
-                traffic_from = f"{pmc_rel}: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this workload, same kernel sources ({sha})"
+                # corrected = FETCH_SIZE / WRITE_SIZE rescaled by the ratios tools/calib_fetch.hip measured on the kernel's own access
+                # shapes (gfx950 tallies 64 B per fabric request, whether it is a 64- or a 128-byte one)
+                traffic = pmc.get("traffic_bytes_corrected") or pmc["traffic_bytes_raw"]
+                traffic_raw = pmc["traffic_bytes_raw"]
+                traffic_from = (f"{pmc_rel}: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this workload, same kernel sources ({sha}); "
+                                f"corrected with {pmc.get('traffic_model', {}).get('calibration', {}).get('file')}")
                 valu = {"busy_fraction": pmc["derived"]["valu_busy_fraction"], "effective_clock_GHz": pmc["derived"]["effective_clock_GHz"],
                         "valu_instr_per_mixed_add": pmc["derived"]["valu_instr_per_mixed_add"], "from": pmc_rel}
             else:
@@ -329,7 +337,7 @@ def main():
             "per_rank": per_rank,
             "weak_scaling_point": weak_point,
             "roofline": {"bound": "hbm", "kernel": "k_accumulate_glds", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_from": traffic_from,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_raw_counter_bytes": traffic_raw, "traffic_from": traffic_from,
                          "kernel_ms": kern_s * 1e3, "algorithmic_bytes_per_launch": BYTES_PER_PAIR[cid] * pairs_per_launch,
                          "valu": valu,
                          "integer": {"mads_per_mixed_add": mads_per_add, "lane_mads_per_s": mad_rate, "peak_lane_mads_per_s": mad_peak,

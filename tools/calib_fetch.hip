@@ -11,7 +11,8 @@
 //   calib_stream8         8 B per lane, coalesced                          (the sorted-entry stream of k_accumulate_glds)
 //   calib_gather_glds<S>  quad-cooperative LDS-DMA gather of S x 64-B records, S = 2, 3, 4   (XYZZ bases 128 B, twisted-Edwards
 //                         192 B, G2 256 B: global_load_lds_dwordx4, lane l of a quad takes piece l of every sector)
-//   calib_gather_lane<S>  one lane per record, S x 64 B by plain 16-B loads (the exceptional-pair re-read, k_segreduce)
+//   calib_gather_lane<S>  one lane per record, S x 64 B by plain 16-B loads: S = 1 is the entry queue's refill (one sector per
+//                         lane, lanes 2 KB apart), S = 2..4 the exceptional-pair re-read and k_segreduce
 //   calib_write16         16 B per lane, coalesced stores
 //   calib_write224        one 224-B bucket record per lane at a random index (seg_flush)
 #include <hip/hip_runtime.h>
@@ -143,6 +144,13 @@ int main() {
     printf("calib_gather_glds<3> %zu\n", (size_t)lanes * it3 * 192);
     hipLaunchKernelGGL(calib_gather_glds<4>, dim3(blocks), dim3(256), 0, 0, table, nrec4, it4, sink);
     printf("calib_gather_glds<4> %zu\n", (size_t)lanes * it4 * 256);
+    {
+      // the entry queue of k_accumulate_glds: one 64-B sector per lane, four 16-B loads back to back, lanes 2 KB apart
+      const uint32_t nrec1 = 1u << 27;   // 8 GiB of 64-B records
+      const uint32_t it1 = nrec1 / lanes / 4;
+      hipLaunchKernelGGL(calib_gather_lane<1>, dim3(blocks), dim3(256), 0, 0, table, nrec1, it1, sink);
+      printf("calib_gather_lane<1> %zu\n", (size_t)lanes * it1 * 64);
+    }
     hipLaunchKernelGGL(calib_gather_lane<2>, dim3(blocks), dim3(256), 0, 0, table, nrec2, it2 / 4, sink);
     printf("calib_gather_lane<2> %zu\n", (size_t)lanes * (it2 / 4) * 128);
     hipLaunchKernelGGL(calib_gather_lane<3>, dim3(blocks), dim3(256), 0, 0, table, nrec3, it3 / 4, sink);

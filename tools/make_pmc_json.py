@@ -1,7 +1,17 @@
 #!/usr/bin/env python3
-"""profiles/r02_pmc_k_accumulate.json from the rocprofv3 passes of tools/profile_gpu.sh (gpurun_out/prof): the counters of the
-headline k_accumulate_glds launch (the largest grid), what is derived from them, and the identity of the kernel sources they
-were measured on (bench.py quotes `roofline.traffic` only when that identity matches the library it runs)."""
+"""profiles/<round>_pmc_k_accumulate[_381|_g2].json from the rocprofv3 passes of tools/profile_gpu.sh: the counters of the headline
+k_accumulate_glds launch (the largest grid), what is derived from them, the identity of the kernel sources they were measured
+on (bench.py quotes `roofline.traffic` only when that identity matches the library it runs) -- and, since round 3, the HBM-side
+byte count CORRECTED with the calibration of tools/calib_fetch.hip (profiles/r03_calib_fetch.txt): on gfx950 FETCH_SIZE is
+64 B x the number of read requests the L2 sends to the fabric, and a request is 64 OR 128 bytes (two adjacent sectors of a line
+asked for together), so the raw figure under-counts by a shape-dependent factor:
+
+    coalesced streams (16 or 8 B per lane)                     0.500
+    quad-cooperative LDS-DMA gather, 128-B / 192-B / 256-B records   0.501 / 0.668 / 0.503
+    one 64-B sector per lane (the entry queue's refill)        see calib_gather_lane<1>
+
+  usage: make_pmc_json.py <prof dir> <out json> <curve: 377|381|g2> [calib table]
+"""
 import csv
 import glob
 import json
@@ -12,11 +22,19 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from bench import kernel_source_sha16  # noqa: E402
 
-prof = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "prof")
-# optional: <out json> <windows> <npow> <window bits> <config text> -- for a second workload (G2: profiles/r02_pmc_k_accumulate_g2.json)
-out_json = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles", "r02_pmc_k_accumulate.json")
-W_, NPOW_, C_ = (int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])) if len(sys.argv) > 5 else (13, 26, 20)
-config_text = sys.argv[6] if len(sys.argv) > 6 else None
+prof, out_json, curve = sys.argv[1], sys.argv[2], sys.argv[3]
+calib_path = sys.argv[4] if len(sys.argv) > 4 else os.path.join(ROOT, "profiles", "r03_calib_fetch.txt")
+CFG = {
+    "377": dict(npow=26, c=20, windows=13, record=192, law="twisted Edwards (7M)", gather="calib_gather_glds<3>", entry="calib_gather_lane<1>", entries_per_refill=8),
+    "381": dict(npow=26, c=20, windows=13, record=128, law="XYZZ (8M + 2S)", gather="calib_gather_glds<2>", entry="calib_gather_lane<1>", entries_per_refill=4),
+    "g2": dict(npow=24, c=20, windows=13, record=256, law="XYZZ over Fq2", gather="calib_gather_glds<4>", entry=None, entries_per_refill=1),
+}[curve]
+calib = {}
+if os.path.exists(calib_path):
+    for line in open(calib_path):
+        f = line.split()
+        if f and f[0].startswith("calib_") and len(f) >= 6:
+            calib[f[0]] = {"fetch_ratio": float(f[3]), "write_ratio": float(f[5])}
 
 
 def headline_counters(tag):
@@ -44,16 +62,48 @@ for f in glob.glob(os.path.join(prof, "stats", "**", "*kernel_trace.csv"), recur
          if "k_accumulate" in r["Kernel_Name"] and int(r["Grid_Size_X"]) == c.get("lanes")]
     if d:
         kern_ms = sum(d) / len(d)
-entries = W_ * (1 << NPOW_) * (1 - 2.0 ** -C_)     # non-zero digits (c = 20, 13 windows at 2^26)
+n = 1 << CFG["npow"]
+entries = CFG["windows"] * n * (1 - 2.0 ** -CFG["c"])     # non-zero digits
+fetch_raw = (c.get("FETCH_SIZE") or 0) * 1024.0
+write_raw = (c.get("WRITE_SIZE") or 0) * 1024.0
+# what the launch has to read, by shape: one base record per entry, the sorted entries (8 B each; a lane that takes one entry
+# per load -- G2 -- asks for a whole sector each time unless the line survived in the L2)
+base_bytes = entries * CFG["record"]
+entry_bytes = entries * 8.0
+r_gather = calib.get(CFG["gather"], {}).get("fetch_ratio")
+r_entry = calib.get(CFG["entry"], {}).get("fetch_ratio") if CFG["entry"] else None
+model = {"base_record_bytes": CFG["record"], "bases_bytes": base_bytes, "entries_bytes": entry_bytes,
+         "algorithmic_bytes_per_pair_SURVEY_8d": 224 if curve == "g2" else 128,
+         "structural_bytes_per_pair": (base_bytes + entry_bytes) / n,
+         "calibration": {"file": os.path.relpath(calib_path, ROOT), "gather_ratio": r_gather, "entry_ratio": r_entry}}
+corrected = None
+if r_gather:
+    if r_entry:
+        predicted_raw = base_bytes * r_gather + entry_bytes * r_entry
+        model["predicted_FETCH_SIZE_bytes_if_every_byte_is_read_once"] = predicted_raw
+        model["measured_over_predicted"] = fetch_raw / predicted_raw if predicted_raw else None
+        # scale the known composition by the measured excess: bytes actually requested from the fabric
+        corrected = (base_bytes + entry_bytes) * (fetch_raw / predicted_raw) if predicted_raw else None
+    else:
+        # entries arrive one per load: every request beyond the base gathers is a 64-B sector fetched for 8 useful bytes
+        sector_requests = max(0.0, fetch_raw - base_bytes * r_gather) / 64.0
+        model["entry_sector_requests"] = sector_requests
+        model["entry_sectors_per_entry"] = sector_requests / entries
+        corrected = base_bytes + sector_requests * 64.0
 res = {
-    "config": config_text or "bls12_377_g1 npow=26 (c = 20, 13 windows), the k_accumulate_glds<TeLaw> launch of a bench step: twisted-Edwards image, "
-              "LDS-DMA quad-cooperative gathers of 192-B records, (value, key) entry stream",
-    "source": "tools/profile_gpu.sh: rocprofv3 --kernel-trace --pmc ..., one counter group per pass; summary in profiles/r02_rocprof_summary.txt",
+    "config": "bls12_%s npow=%d (c = %d, %d windows), the k_accumulate_glds launch of a bench step: %s, LDS-DMA quad-cooperative gathers of %d-B "
+              "records, sorted (value, key) entries %s" % ({"377": "377_g1", "381": "381_g1", "g2": "377_g2"}[curve], CFG["npow"], CFG["c"], CFG["windows"], CFG["law"],
+                                                           CFG["record"], "through a register queue (%d per refill)" % CFG["entries_per_refill"] if CFG["entry"] else "one per load"),
+    "source": "tools/profile_gpu.sh: rocprofv3 --kernel-trace --pmc ..., one counter group per pass",
     "kernel_source_sha16": kernel_source_sha16(),
     "FETCH_SIZE_KiB": c.get("FETCH_SIZE"), "WRITE_SIZE_KiB": c.get("WRITE_SIZE"),
-    "traffic_bytes_raw": (c.get("FETCH_SIZE", 0) + c.get("WRITE_SIZE", 0)) * 1024.0,
-    "note": "gfx950 FETCH_SIZE counts one 64-B unit per EA read request (coalesced 16 B/lane streams read 0.5x, see MI355X_MICROARCH.md); the "
-            "cooperative gather requests whole 64-B sectors (three per record) plus the 8-B entries, so the raw figure is taken as the byte count",
+    "traffic_bytes_raw": fetch_raw + write_raw,
+    "traffic_bytes_corrected": (corrected + write_raw) if corrected else None,
+    "traffic_model": model,
+    "note": "gfx950 FETCH_SIZE = 64 B x fabric read requests, a request being 64 or 128 B; `traffic_bytes_corrected` rescales the raw figure by the ratios "
+            "measured on the same access shapes with known byte counts (tools/calib_fetch.hip). WRITE_SIZE is exact for coalesced stores and 1.28x for "
+            "scattered 224-B records (partial sectors), left as reported. Infinity-Cache hits are counted, not excluded: this is traffic at the L2's "
+            "fabric port, an upper bound on what HBM moves.",
     "SQ_INSTS_VALU": c.get("SQ_INSTS_VALU"), "SQ_WAVE_CYCLES_quad": c.get("SQ_WAVE_CYCLES"), "SQ_ACTIVE_INST_VALU_quad": c.get("SQ_ACTIVE_INST_VALU"),
     "SQ_WAIT_INST_ANY_quad": c.get("SQ_WAIT_INST_ANY"), "SQ_WAIT_ANY_quad": c.get("SQ_WAIT_ANY"), "GRBM_GUI_ACTIVE": c.get("GRBM_GUI_ACTIVE"),
     "kernel_ms_rocprof": kern_ms, "lanes": c.get("lanes"),
@@ -65,5 +115,7 @@ if c.get("SQ_INSTS_VALU"):
     res["derived"]["valu_instr_per_mixed_add"] = c["SQ_INSTS_VALU"] * 64 / entries
 if c.get("SQ_ACTIVE_INST_VALU") and c.get("GRBM_GUI_ACTIVE"):
     res["derived"]["valu_busy_fraction"] = c["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / (c["GRBM_GUI_ACTIVE"] / 8)
+if kern_ms and corrected:
+    res["derived"]["fabric_read_TBps"] = corrected / (kern_ms * 1e-3) / 1e12
 json.dump(res, open(out_json, "w"), indent=1)
 print(json.dumps(res, indent=1))
