@@ -175,6 +175,9 @@ __global__ void __launch_bounds__(256, G::ACC_WAVES) k_accumulate_glds(const uin
 #ifndef MSM_ACC_LDS_PAD
 #define MSM_ACC_LDS_PAD 0   // A/B only: extra LDS per wave lowers the number of resident blocks (profiles/r03_ab_occupancy.txt)
 #endif
+#ifndef MSM_ACC_PRIO
+#define MSM_ACC_PRIO 0      // A/B only (profiles/r03_ab_setprio.txt): 1 = s_setprio 2 around the addition (a wave in its MAD-dense
+#endif                      // phase runs ahead of the waves that gather), 2 = around the gather phase, 3 = odd waves start late
   constexpr int WAVE_LDS = 4 * SECT * RS + 256 + MSM_ACC_LDS_PAD;
   static_assert(sizeof(typename G::BaseDev) % 64 == 0 && SECT >= 2 && SECT <= 4, "record layout");
   __shared__ __attribute__((aligned(16))) unsigned char lds[4 * WAVE_LDS];
@@ -267,9 +270,15 @@ __global__ void __launch_bounds__(256, G::ACC_WAVES) k_accumulate_glds(const uin
   bool first = true, fresh = true, bad = false;
   XyzzT<typename G::T> acc;
   G::set_identity(acc);
+#if MSM_ACC_PRIO == 3
+  if (wave & 1) __builtin_amdgcn_s_sleep(127);
+#endif
   for (uint32_t k = 0; k < K; k++) {
     if (__builtin_amdgcn_ballot_w64(alive) == 0) break;   // wave-uniform: every lane of the wave has run out
     Base p;
+#if MSM_ACC_PRIO == 2
+    __builtin_amdgcn_s_setprio(2);
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the DMA of this entry's records has landed
     __builtin_amdgcn_wave_barrier();
     G::load_sectors(p, rec, RS, alive && (val_c >> 31) != 0);
@@ -294,6 +303,9 @@ __global__ void __launch_bounds__(256, G::ACC_WAVES) k_accumulate_glds(const uin
       key_n = e2.y;
       val_n = e2.x;
     }
+#if MSM_ACC_PRIO == 2
+    __builtin_amdgcn_s_setprio(0);
+#endif
     if (add_now) {
       if (key != cur) {
         if (cur != KEY_NONE) {
@@ -304,11 +316,17 @@ __global__ void __launch_bounds__(256, G::ACC_WAVES) k_accumulate_glds(const uin
         fresh = true;
         G::begin_run(acc);
       }
+#if MSM_ACC_PRIO == 1
+      __builtin_amdgcn_s_setprio(2);
+#endif
       if (G::madd_loaded(acc, p, (val >> 31) != 0, fresh, md)) {
         // exceptional pair (short Weierstrass only): the record in LDS is already being overwritten, so fetch it again
         const Base again = G::from_dev(bases[val & IDX_MASK]);
         G::madd_same_x(acc, again, (val >> 31) != 0, md);
       }
+#if MSM_ACC_PRIO == 1
+      __builtin_amdgcn_s_setprio(0);
+#endif
       if (G::CHECKS) bad |= G::failed(acc);
       fresh = false;
     }
