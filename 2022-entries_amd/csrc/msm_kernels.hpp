@@ -170,16 +170,19 @@ __global__ void __launch_bounds__(256, G::ACC_WAVES) k_accumulate_glds(const uin
                                                          SegOutT<typename G::T> out, uint32_t nlanes, uint32_t* __restrict__ flags) {
   using E = typename G::E;
   using Base = typename G::Base;
-  constexpr int SECT = sizeof(typename G::BaseDev) / 64;   // 64-B sectors per record
+  constexpr int SECT = G::GATHER_SECTORS;                  // 64-B sectors per record
   constexpr int RS = 1024;                                 // bytes of one (record index, sector) region: 64 lanes x 16 B
 #ifndef MSM_ACC_LDS_PAD
 #define MSM_ACC_LDS_PAD 0   // A/B only: extra LDS per wave lowers the number of resident blocks (profiles/r03_ab_occupancy.txt)
 #endif
+#ifndef MSM_ACC_IDX_AND
+#define MSM_ACC_IDX_AND 0xffffffffu   // A/B only (profiles/r03_ab_power.txt): gather from a small subset of the records (wrong sums,
+#endif                                 // same instructions) to see what the memory path costs in power, i.e. in clock
 #ifndef MSM_ACC_PRIO
 #define MSM_ACC_PRIO 0      // A/B only (profiles/r03_ab_setprio.txt): 1 = s_setprio 2 around the addition (a wave in its MAD-dense
 #endif                      // phase runs ahead of the waves that gather), 2 = around the gather phase, 3 = odd waves start late
   constexpr int WAVE_LDS = 4 * SECT * RS + 256 + MSM_ACC_LDS_PAD;
-  static_assert(sizeof(typename G::BaseDev) % 64 == 0 && SECT >= 2 && SECT <= 4, "record layout");
+  static_assert(sizeof(typename G::BaseDev) % 64 == 0 && SECT >= 2 && SECT <= 4 && SECT * 64 <= (int)sizeof(typename G::BaseDev), "record layout");
   __shared__ __attribute__((aligned(16))) unsigned char lds[4 * WAVE_LDS];
   const uint32_t t = blockIdx.x * 256 + threadIdx.x;
   const uint32_t lane = threadIdx.x & 63, sub = lane & 3, quad = lane >> 2;
@@ -258,7 +261,7 @@ __global__ void __launch_bounds__(256, G::ACC_WAVES) k_accumulate_glds(const uin
   } while (0)
 #define MSM_GLDS_ISSUE(val, valid)                                \
   do {                                                            \
-    const int mine_ = (valid) ? (int)((val) & IDX_MASK) : 0;      \
+    const int mine_ = (valid) ? (int)((val) & IDX_MASK & MSM_ACC_IDX_AND) : 0; \
     MSM_GLDS_ONE(0, 0x00);                                        \
     MSM_GLDS_ONE(1, 0x55);                                        \
     MSM_GLDS_ONE(2, 0xaa);                                        \
@@ -289,7 +292,9 @@ __global__ void __launch_bounds__(256, G::ACC_WAVES) k_accumulate_glds(const uin
     key_c = key_n;
     val_c = val_n;
     alive = add_now && (end - e > 1);
+#ifndef MSM_ACC_NO_GATHER   // A/B only: defined = the records gathered before the loop are reused for every addition (no base traffic)
     MSM_GLDS_ISSUE(val_c, alive);
+#endif
     if constexpr (EQ > 0) {
       MSM_Q_POP(key_n, val_n);   // entry e + 2
       // the pop that empties the queue starts the refill: the loads are in flight during this iteration's addition and are

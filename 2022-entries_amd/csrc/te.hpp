@@ -30,7 +30,10 @@ struct TeAffine {
 // Device record: ONE FIELD PER 64-B SECTOR (56 B + 8 B of padding), 192 B.  A gather touches exactly three sectors, and a
 // kernel that receives the record sector by sector (k_accumulate_glds) applies the negation swap by choosing which sector it
 // reads Y - X from.
-struct alignas(64) TeAffineDev {
+#ifndef TE_REC_PAD256
+#define TE_REC_PAD256 0   // A/B only (profiles/r03_ab_power.txt): 1 = records 256 bytes apart, so that none straddles a 256-byte boundary
+#endif
+struct alignas(TE_REC_PAD256 ? 256 : 64) TeAffineDev {
   Fe ymx;
   uint32_t pad0[2];
   Fe ypx;
@@ -51,7 +54,7 @@ struct alignas(64) TeAffineDev {
     pad0[0] = pad0[1] = pad1[0] = pad1[1] = pad2[0] = pad2[1] = 0;
   }
 };
-static_assert(sizeof(TeAffineDev) == 192, "device twisted-Edwards base layout");
+static_assert(sizeof(TeAffineDev) == (TE_REC_PAD256 ? 256 : 192), "device twisted-Edwards base layout");
 
 template <class F>
 MSM_HD void te_set_identity(Xyzz& r) {
