@@ -178,6 +178,9 @@ __global__ void __launch_bounds__(256, G::ACC_WAVES) k_accumulate_glds(const uin
 #ifndef MSM_ACC_IDX_AND
 #define MSM_ACC_IDX_AND 0xffffffffu   // A/B only (profiles/r03_ab_power.txt): gather from a small subset of the records (wrong sums,
 #endif                                 // same instructions) to see what the memory path costs in power, i.e. in clock
+#ifndef MSM_ACC_IDX_SHL
+#define MSM_ACC_IDX_SHL 0             // A/B only: spread the masked subset over the whole table (same cache footprint, full TLB footprint)
+#endif
 #ifndef MSM_ACC_PRIO
 #define MSM_ACC_PRIO 0      // A/B only (profiles/r03_ab_setprio.txt): 1 = s_setprio 2 around the addition (a wave in its MAD-dense
 #endif                      // phase runs ahead of the waves that gather), 2 = around the gather phase, 3 = odd waves start late
@@ -261,7 +264,7 @@ __global__ void __launch_bounds__(256, G::ACC_WAVES) k_accumulate_glds(const uin
   } while (0)
 #define MSM_GLDS_ISSUE(val, valid)                                \
   do {                                                            \
-    const int mine_ = (valid) ? (int)((val) & IDX_MASK & MSM_ACC_IDX_AND) : 0; \
+    const int mine_ = (valid) ? (int)((((val) & IDX_MASK & MSM_ACC_IDX_AND)) << MSM_ACC_IDX_SHL) : 0; \
     MSM_GLDS_ONE(0, 0x00);                                        \
     MSM_GLDS_ONE(1, 0x55);                                        \
     MSM_GLDS_ONE(2, 0xaa);                                        \
