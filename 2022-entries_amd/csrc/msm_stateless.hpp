@@ -161,10 +161,15 @@ struct Uploader : msm_host::UploaderT<HipPipelineApi> {
   }
 };
 
-// Slice bounds: a short first slice so that the first kernels start early (the growing chunks of P1A matter-labs/src/lib.rs:171-182).
-std::vector<size_t> stateless_slices(size_t n, size_t slice) {
+// Slice bounds: short first slices so that the first kernels start early (the growing chunks of P1A matter-labs/src/lib.rs:171-182).
+// ramp = 1: slice/8, slice/2, then full slices -- the compute side waits for 1/8 slice instead of 1/2 before its first kernel;
+// ramp = 0: slice/2, then full slices (the first version; kept for the A/B of profiles/r03_stateless_probe.txt).
+std::vector<size_t> stateless_slices(size_t n, size_t slice, int ramp) {
   std::vector<size_t> lo{0};
-  if (n > slice + slice / 2) lo.push_back(slice / 2);
+  if (n > slice + slice / 2) {
+    if (ramp && slice >= 64) lo.push_back(slice / 8);
+    lo.push_back(lo.back() + slice / 2);
+  }
   while (lo.back() + slice < n) {
     // do not leave a sliver for the last slice: it would pay a whole bucket reduction for a few pairs
     if (n - (lo.back() + slice) < slice / 4) break;
@@ -198,7 +203,7 @@ void stateless_t(mi355_msm_ctx* ctx, uint8_t* out, const uint8_t* affine, size_t
     // overlap) and 2^23 (1.1 GB: 20 ms of PCIe against ~20 ms of compute)
     const long auto_log = std::min<long>(23, std::max<long>(20, (long)ilog2_floor(std::max<size_t>(n, 4) / 4)));
     const size_t slice = (size_t)1 << env_long("MI355_MSM_STATELESS_SLICE_LOG", auto_log, 10, 26);
-    const std::vector<size_t> lo = stateless_slices(n, slice);
+    const std::vector<size_t> lo = stateless_slices(n, slice, (int)env_long("MI355_MSM_STATELESS_RAMP", 1, 0, 1));
     const uint32_t S = (uint32_t)lo.size() - 1;
     size_t max_cnt = 0;
     for (uint32_t s = 0; s < S; s++) max_cnt = std::max(max_cnt, lo[s + 1] - lo[s]);
@@ -228,7 +233,7 @@ void stateless_t(mi355_msm_ctx* ctx, uint8_t* out, const uint8_t* affine, size_t
         bool fits = true;
         for (uint32_t s = 0; s < S; s++) {
           const size_t cnt = lo[s + 1] - lo[s];
-          if (s > 1 && s + 1 < S) continue;   // the slices in between have the size of slice 1
+          if (s > 2 && s + 1 < S) continue;   // the slices in between have the size of slice 2
           const Plan p = ctx->plan(cnt, false);
           fits = fits && p.entries < (1ull << 32);
           w.max_with(chunk_work_bytes(p, cnt, false, sizeof(XyzzDevT<typename E::T>)));

@@ -162,7 +162,8 @@ RustError mi355_msm(int curve, void* out_projective, const void* affine, size_t 
  * while the current one is sorted and accumulated; CMB MSM.cu:419-434; the growing chunks of P1A matter-labs/src/lib.rs:171-182):
  * slices of 2^20..2^23 pairs are staged by a few host threads through a small ring of pinned buffers (kept for the life of the
  * process; mi355_msm_trim() gives it back) and cross PCIe while earlier slices are converted and run; partial sums are added
- * on the host.  Environment: MI355_MSM_STAGE_THREADS (default 6), MI355_MSM_STATELESS_SLICE_LOG (log2 pairs per slice).
+ * on the host.  Environment: MI355_MSM_STAGE_THREADS (default 6), MI355_MSM_STATELESS_SLICE_LOG (log2 pairs per slice),
+ * MI355_MSM_STATELESS_RAMP (default 1: the first two slices are 1/8 and 1/2 of a slice; 0: one half slice first).
  * With MI355_MSM_DEVICES naming several GPUs every shard runs its own pipeline over its slice of both operands.
  * mi355_msm_last_stateless: what the calling thread's most recent stateless call did -- out[0..7] = total ms, setup ms (buffers,
  * ring, threads), ms the compute side waited for uploads, ms it spent issuing/awaiting slices, the last slice's share of that

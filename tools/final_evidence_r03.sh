@@ -12,6 +12,8 @@ for t in "prof 377 " "prof_381 381 _381" "prof_g2 g2 _g2"; do
   set -- $t
   python tools/make_pmc_json.py gpurun_out/$1 gpurun_out/r03_pmc_k_accumulate${3:-}.json $2 gpurun_out/r03_calib_fetch.txt > /dev/null 2>&1
   cp gpurun_out/$1/summary.txt gpurun_out/r03_rocprof_summary${3:-}.txt
+  # bench.py quotes roofline.traffic from profiles/ when the counters were measured on the kernel sources it runs: these were
+  cp gpurun_out/r03_pmc_k_accumulate${3:-}.json profiles/
 done
 python -m pytest tests -m gpu -q 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl" | tail -4 > gpurun_out/r03_pytest_gpu.txt
 python bench.py > gpurun_out/r03_bench.json 2> gpurun_out/r03_bench.err
