@@ -30,6 +30,8 @@ struct Launch {
   // small windows: one step of the scan-based reduction (k_reduce_scan_step)
   static hipError_t reduce_scan_step(const XyzzDevT<El>* in, const XyzzDevT<El>* in2, XyzzDevT<El>* out, uint32_t nb, uint32_t windows, uint32_t d, uint32_t mode,
                                      uint32_t quad_limit, hipStream_t st);
+  // carried buckets: total[b] += part[b] (k_bucket_merge)
+  static hipError_t bucket_merge(XyzzDevT<El>* total, const XyzzDevT<El>* part, uint32_t n, hipStream_t st);
 };
 
 // The twisted-Edwards fast path of BLS12-377 G1 (kernels_377te.hip).  `flags`: [0] += bases without an image (convert),
@@ -46,6 +48,7 @@ struct LaunchTe {
                                   uint32_t windows, XyzzDev* out_a, XyzzDev* out_x, uint32_t* flags, hipStream_t st);
   static hipError_t reduce_scan_step(const XyzzDev* in, const XyzzDev* in2, XyzzDev* out, uint32_t nb, uint32_t windows, uint32_t d, uint32_t mode,
                                      uint32_t quad_limit, uint32_t* flags, hipStream_t st);
+  static hipError_t bucket_merge(XyzzDev* total, const XyzzDev* part, uint32_t n, uint32_t* flags, hipStream_t st);
 };
 
 // Bucket grouping (partition.hip): digits + MSD partition of the (key, value) entries.  scalar_field: 0 = BLS12-377 Fr, 1 = BLS12-381 Fr

@@ -73,6 +73,12 @@ hipError_t Launch<E>::reduce_scan_step(const XyzzDevT<El>* in, const XyzzDevT<El
 }
 
 template <class E>
+hipError_t Launch<E>::bucket_merge(XyzzDevT<El>* total, const XyzzDevT<El>* part, uint32_t n, hipStream_t st) {
+  hipLaunchKernelGGL((k_bucket_merge<SwLaw<E>>), dim3(launch_blocks(n)), dim3(256), 0, st, total, part, n, (uint32_t*)nullptr);
+  return hipGetLastError();
+}
+
+template <class E>
 hipError_t Launch<E>::pre_double(const AffineDevT<El>* in, const uint8_t* inf_in, uint32_t n, uint32_t c, XyzzDevT<El>* out, hipStream_t st) {
   hipLaunchKernelGGL((k_pre_double<E>), dim3(launch_blocks(n)), dim3(256), 0, st, in, inf_in, n, c, out);
   return hipGetLastError();

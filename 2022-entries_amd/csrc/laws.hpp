@@ -72,6 +72,7 @@ struct SwLaw {
   }
   static MSM_HD bool failed(const XyzzT<T>&) { return false; }
   static MSM_HD bool is_empty(const XyzzT<T>&) { return false; }   // XYZZ: all-zero IS the identity
+  static MSM_HD bool nothing(const XyzzT<T>& a) { return xyzz_is_inf<E>(a); }   // adds nothing: an empty bucket or the identity
 };
 
 template <class F>
@@ -135,6 +136,7 @@ struct TeLaw {
   }
   static MSM_HD bool failed(const Xyzz& a) { return te_failed<F>(a); }
   static MSM_HD bool is_empty(const Xyzz& a) { return fe_is_zero_M<F>(a.zz); }   // Z = 0 never occurs in a valid point
+  static MSM_HD bool nothing(const Xyzz& a) { return fe_is_zero_M<F>(a.zz); }    // an empty bucket (the identity (0, 1, 1, 0) is added like any point)
 };
 
 }  // namespace msm

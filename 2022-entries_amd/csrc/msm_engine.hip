@@ -136,7 +136,7 @@ inline uint32_t ilog2_floor(uint64_t v) { uint32_t r = 0; while (v >>= 1) r++; r
 // top window is only partly populated: with `rem` significant bits left it behaves like a full window, with none it
 // only ever receives the signed-digit carry (about half of the scalars).  Buckets exist for all ceil(257/c) windows (any 256-bit
 // scalar is legal), or for ONE window when precomputed tables let all digits share a bucket set.
-int choose_window_bits(size_t n, int scalar_bits, bool shared_buckets) {
+int choose_window_bits(size_t n, int scalar_bits, bool shared_buckets, bool fold = false) {
   // Between 2^12 and 2^19 pairs an MSM is latency, not throughput: what a window size costs is the launches it implies
   // (two scan steps of the bucket reduction per bit, a grouping pass more from 12 bits on, per-window steps of the level-1
   // tiles) and the model below does not see them.  Measured on all three curves (tools/small_c_sweep.py,
@@ -149,8 +149,11 @@ int choose_window_bits(size_t n, int scalar_bits, bool shared_buckets) {
   int best = 2;
   double best_cost = 1e300;
   for (int c = 2; c <= (shared_buckets ? 24 : 23); c++) {
-    const int full = scalar_bits / c, rem = scalar_bits - full * c;
-    const double eff = full + (rem >= 2 ? 1.0 : 0.55);
+    // folded scalars (assume_subgroup) are < r/2: one bit less, and when c divides that the window above only takes the carry
+    // of the scalars whose top digit exceeds 2^(c-1): (r/2 - 2^(bits-1)) / (r/2) = 14.5 % (BLS12-377), 44.8 % (BLS12-381)
+    const int bits = fold ? scalar_bits - 1 : scalar_bits;
+    const int full = bits / c, rem = bits - full * c;
+    const double eff = full + (rem >= 2 ? 1.0 : (fold && rem == 0 ? (scalar_bits == 253 ? 0.145 : 0.448) : 0.55));
     const double alloc = shared_buckets ? 1.0 : (double)((257 + c - 1) / c);
     const double cost = eff * (double)n * 10.0 + alloc * (double)(1ull << (c - 1)) * 50.0;
     if (cost < best_cost) { best_cost = cost; best = c; }
@@ -179,17 +182,22 @@ struct mi355_msm_ctx {
   int device = 0;
   hipStream_t own_stream = nullptr;
   hipStream_t copy_stream = nullptr;   // H2D of the next scalar batch while the current one computes
-  hipEvent_t copy_ev[3] = {};   // batch parity 0/1 resident, first piece of batch 0 resident
+  hipEvent_t copy_ev[9] = {};   // batch parity 0/1 resident, pieces 0..6 of batch 0 resident
   size_t nbases = 0;
   DevBuf bases, inf;
   DevBuf stateless_raw[3];   // raw base records of the stateless pipeline (msm_stateless.hpp), kept with a cached context
   DevBuf scalars, entries[2], buckets, slots[2], slot_keys[2], red_a[2], red_x[2];
+  DevBuf carry_buckets;      // the bucket array a multi-chunk batch carries from chunk to chunk (k_bucket_merge)
+  std::vector<hipEvent_t> carry_ev;   // stage events of the chunks of such a batch (7 per chunk; they are read after the batch's only synchronisation)
+  long opt_first_piece_div = 0;   // the first piece of a host-scalar batch is 1/div of it (0 = the default)
+  long opt_carry = 1;        // 0: every chunk reduces its own buckets and the partial sums are added on the host (the A/B of profiles/r03_ab_carry.txt)
   DevBuf part_matrix, part_partial, part_segs[2], part_subjobs, part_counts, part_totals;   // bucket grouping scratch (partition_plan.hpp)
   void* pinned = nullptr;  // window sums land here
   size_t pinned_bytes = 0;
   hipEvent_t ev[8] = {};
   long opt_window_bits = 0, opt_lane_entries = 0, opt_max_chunk = 0, opt_seg_entries = 0, opt_scalars_montgomery = 0, opt_reduce_scan_log = 0;
   long opt_precompute = 0;
+  long opt_assume_subgroup = 0;   // 1: every base is in the order-r subgroup (r P = O), so a scalar k in (r/2, r) may run as (r - k)(-P)
   long opt_reduce_log_chunk = 0, opt_reduce_log_chunk0 = 0;
   long opt_reduce_scan = -1;      // 0: recursive chunked running sums only; otherwise the scan tail (default)
   long opt_twisted_edwards = 1;   // BLS12-377 G1 only: accumulate on the twisted-Edwards image when every base has one
@@ -205,8 +213,9 @@ struct mi355_msm_ctx {
   size_t chunk_cap = 0;           // what the most recent run had to cap its chunks at after an allocation failed (0 = it never had to); reported, not kept
   size_t fitted_chunk = 0;        // largest chunk that has run with the current buffers and options (skips the fit query)
   bool fitted_tables = false;
+  uint32_t fitted_c = 0;          // ... under this forced window size (0 = each chunk plans its own)
   long opt_mem_limit = 0;         // test hook: pretend the device has at most this many free bytes when sizing chunks
-  long inject_alloc_failures = 0; // test hook: the next N work-buffer reservations of THIS context fail as if HBM were exhausted
+  long inject_alloc_failures = 0; // test hook: the next N work-buffer reservations of THIS context fail as if HBM were exhausted (-K: only the K-th from now)
   uint32_t quad_limit = LaunchTe::kDefaultQuadLimit;   // merge / scan launches of at most this many additions run four lanes per addition
   // sharded context (mi355_msm_create_sharded): this object then owns no device state itself, only the per-device children
   std::vector<mi355_msm_ctx*> shards;
@@ -224,13 +233,16 @@ struct mi355_msm_ctx {
 
   // use_tables = false plans the run WITHOUT the precomputed tables of this context (the XYZZ fallback of a
   // twisted-Edwards context, whose short-Weierstrass tables were dropped)
-  Plan plan(size_t n, bool use_tables = true) const {
+  // `force_c`: the window size of the whole batch when it runs as several chunks over carried buckets (run_device_t)
+  Plan plan(size_t n, bool use_tables = true, uint32_t force_c = 0) const {
     Plan p{};
     const bool tables = pre_c && use_tables;
     if (tables)
       p.c = pre_c;
+    else if (force_c)
+      p.c = force_c;
     else
-      p.c = (opt_window_bits && !pre_c) ? (uint32_t)opt_window_bits : (uint32_t)choose_window_bits(n, scalar_bits(), false);
+      p.c = (opt_window_bits && !pre_c) ? (uint32_t)opt_window_bits : (uint32_t)choose_window_bits(n, scalar_bits(), false, opt_assume_subgroup != 0);
     p.windows = (257 + p.c - 1) / p.c;
     p.bucket_windows = tables ? 1 : p.windows;
     p.half = 1u << (p.c - 1);
@@ -303,18 +315,18 @@ hipStream_t create_copy_stream() {
 }
 
 // Device bytes of the per-run work buffers of one chunk (keys/vals x2, buckets, slots x2, reduce x4); `el` = 2 for Fq2 points.
-uint64_t work_bytes(const Plan& p, uint64_t el) {
+uint64_t work_bytes(const Plan& p, uint64_t el, bool carry = false) {
   const PartPlan pp = part_plan((uint32_t)(p.entries / p.windows), p.c, p.windows, p.bucket_windows == 1 && p.windows > 1, 0, 0);
   const PartScratchSizes ps = part_scratch_sizes(pp);
   return p.entries * 16 + ps.matrix + ps.partial + ps.segs_a + ps.segs_b + ps.subjob_first + ps.counts + ps.totals +
-         (uint64_t)p.bucket_windows * p.half * 224 * el + 2 * (2ull * p.nlanes) * (224 * el + 4) + (p.scan_direct ? (uint64_t)p.bucket_windows * p.half : 4ull * p.bucket_windows * p.T0) * 224 * el;
+         (uint64_t)p.bucket_windows * p.half * 224 * el * (carry ? 2 : 1) + 2 * (2ull * p.nlanes) * (224 * el + 4) + (p.scan_direct ? (uint64_t)p.bucket_windows * p.half : 4ull * p.bucket_windows * p.T0) * 224 * el;
 }
 
 DevBuf* const* work_buffers(mi355_msm_ctx* ctx, size_t& count) {
   static thread_local DevBuf* bufs[24];
   DevBuf* list[] = {&ctx->entries[0], &ctx->entries[1], &ctx->part_matrix, &ctx->part_partial, &ctx->part_segs[0], &ctx->part_segs[1],
                     &ctx->part_subjobs, &ctx->part_counts, &ctx->part_totals, &ctx->buckets, &ctx->slots[0], &ctx->slots[1],
-                    &ctx->slot_keys[0], &ctx->slot_keys[1], &ctx->red_a[0], &ctx->red_a[1], &ctx->red_x[0], &ctx->red_x[1]};
+                    &ctx->slot_keys[0], &ctx->slot_keys[1], &ctx->red_a[0], &ctx->red_a[1], &ctx->red_x[0], &ctx->red_x[1], &ctx->carry_buckets};
   count = sizeof list / sizeof list[0];
   for (size_t i = 0; i < count; i++) bufs[i] = list[i];
   return bufs;
@@ -324,13 +336,13 @@ DevBuf* const* work_buffers(mi355_msm_ctx* ctx, size_t& count) {
 // plan p (`xyzz` = sizeof(XyzzDev) of the curve).  Separate from the reservation so that a caller that knows all its chunk
 // sizes in advance (the stateless pipeline) can take the element-wise maximum and allocate ONCE.
 struct WorkBytes {
-  size_t b[18] = {};
+  size_t b[19] = {};
   void max_with(const WorkBytes& o) {
-    for (int i = 0; i < 18; i++) b[i] = std::max(b[i], o.b[i]);
+    for (int i = 0; i < 19; i++) b[i] = std::max(b[i], o.b[i]);
   }
 };
 
-WorkBytes chunk_work_bytes(const Plan& p, size_t n, bool use_tables, size_t xyzz) {
+WorkBytes chunk_work_bytes(const Plan& p, size_t n, bool use_tables, size_t xyzz, bool carry = false) {
   WorkBytes w;
   const PartPlan gp = part_plan((uint32_t)n, p.c, p.windows, use_tables, 0, 0);
   const PartScratchSizes gs = part_scratch_sizes(gp);
@@ -350,6 +362,7 @@ WorkBytes chunk_work_bytes(const Plan& p, size_t n, bool use_tables, size_t xyzz
   w.b[14] = red0 * xyzz;                          // red_a[0]
   w.b[15] = p.scan_direct ? 0 : red0 * xyzz;      // red_a[1]
   w.b[16] = w.b[17] = p.scan_direct ? 0 : red0 * xyzz;   // red_x[0], red_x[1]
+  w.b[18] = carry ? nbuckets * xyzz : 0;          // carry_buckets: the same size as `buckets` (the two change places after the first chunk)
   return w;
 }
 
@@ -362,7 +375,7 @@ void reserve_work(mi355_msm_ctx* ctx, const WorkBytes& w) {
 
 // The largest chunk (<= want) whose work buffers fit the device memory that is free now or already held by this context
 // for the purpose -- the reference plans its allocations before it runs, too (ML msm.cu:453-466).  Halves until it fits.
-size_t fit_chunk(mi355_msm_ctx* ctx, size_t want, bool use_tables) {
+size_t fit_chunk(mi355_msm_ctx* ctx, size_t want, bool use_tables, uint32_t force_c = 0) {
   size_t free_b = 0, total_b = 0;
   HIP_OK(hipMemGetInfo(&free_b, &total_b));
   size_t held = 0, nb = 0;
@@ -373,19 +386,21 @@ size_t fit_chunk(mi355_msm_ctx* ctx, size_t want, bool use_tables) {
   const uint64_t el = ctx->curve == MI355_BLS12_377_G2 ? 2 : 1;
   size_t cn = want;
   while (cn > 1024) {
-    const Plan p = ctx->plan(cn, use_tables);
+    const Plan p = ctx->plan(cn, use_tables, force_c);
     // 3 % head-room for the sort's temporary storage and allocator granularity
-    if (p.entries < (1ull << 32) && work_bytes(p, el) + (work_bytes(p, el) >> 5) <= avail) break;
+    if (p.entries < (1ull << 32) && work_bytes(p, el, force_c != 0) + (work_bytes(p, el, force_c != 0) >> 5) <= avail) break;
     cn = (cn + 1) / 2;
   }
   return cn;
 }
 
-void release_work_buffers(mi355_msm_ctx* ctx) {
+// `keep_carry`: a carried batch is under way -- its bucket totals survive (an allocation failure then costs a smaller chunk, not the batch)
+void release_work_buffers(mi355_msm_ctx* ctx, bool keep_carry = false) {
   ctx->fitted_chunk = 0;
   size_t nb = 0;
   DevBuf* const* wb = work_buffers(ctx, nb);
-  for (size_t i = 0; i < nb; i++) wb[i]->release();
+  for (size_t i = 0; i < nb; i++)
+    if (!(keep_carry && wb[i] == &ctx->carry_buckets)) wb[i]->release();
 }
 
 // Run `fn.template operator()<Curve>()` for the curve id.
@@ -581,9 +596,28 @@ __global__ void __launch_bounds__(256) k_collect_sums(const uint4* __restrict__ 
 // One chunk of one batch: device scalars [0, n) against bases [base0, base0 + n).  Leaves the folded chunk sum in `out`.
 // TE = true runs the twisted-Edwards kernels (BLS12-377 G1 contexts whose bases all have an image) and returns false when
 // an addition reported a vanishing denominator: the caller then repeats the chunk with TE = false.
+// A batch that runs as several chunks carries ONE bucket array through them (k_bucket_merge): every chunk groups and accumulates
+// with the window size of the whole batch, chunk 0's buckets become the batch's, the later ones are added to them, and only the
+// last chunk reduces, synchronises and folds.  The chunks before it return the identity and leave their kernels in flight.
+struct BucketCarry {
+  uint32_t c;        // window bits of the batch
+  uint32_t index;    // chunk number within the batch (selects its stage events)
+  bool first, last;
+};
+
+// stage events of chunk `index` of a carried batch (the single-chunk path keeps ctx->ev)
+hipEvent_t* carry_events(mi355_msm_ctx* ctx, uint32_t index) {
+  while (ctx->carry_ev.size() < 7 * ((size_t)index + 1)) {
+    hipEvent_t e = nullptr;
+    HIP_OK(hipEventCreate(&e));
+    ctx->carry_ev.push_back(e);
+  }
+  return ctx->carry_ev.data() + 7 * (size_t)index;
+}
+
 template <class C, bool TE>
 bool run_chunk_impl(mi355_msm_ctx* ctx, const uint32_t* d_scalars, size_t base0, size_t n, hipStream_t st,
-                    typename HostTail<typename C::E>::Pt& out, const std::function<void()>* while_gpu_busy) {
+                    typename HostTail<typename C::E>::Pt& out, const std::function<void()>* while_gpu_busy, const BucketCarry* carry = nullptr) {
   using E = typename C::E;
   using El = typename E::T;
   using XyzzDev = XyzzDevT<El>;
@@ -591,16 +625,18 @@ bool run_chunk_impl(mi355_msm_ctx* ctx, const uint32_t* d_scalars, size_t base0,
   using SegOut = SegOutT<El>;
   using Xyzz = XyzzT<El>;
   const bool use_tables = ctx->pre_c && (TE || !ctx->sw_level0_only);
-  const Plan p = ctx->plan(n, use_tables);
+  const Plan p = ctx->plan(n, use_tables, carry ? carry->c : 0);
   if (p.entries >= (1ull << 32)) bad_arg("chunk of %zu pairs needs %llu sort entries (>= 2^32)", n, (unsigned long long)p.entries);
+  hipEvent_t* const ev = carry ? carry_events(ctx, carry->index) : ctx->ev;
   const size_t NE = p.entries;
-  if (ctx->inject_alloc_failures > 0) {
-    ctx->inject_alloc_failures--;
-    throw HipFailure((int)hipErrorOutOfMemory, "work-buffer reservation failed: out of memory (injected by the inject_alloc_failures test hook)");
+  if (ctx->inject_alloc_failures != 0) {
+    // N > 0: the next N reservations fail; -K: the K-th reservation from now fails (a chunk in the middle of a carried batch)
+    const bool fail = ctx->inject_alloc_failures > 0 ? (ctx->inject_alloc_failures--, true) : (++ctx->inject_alloc_failures == 0);
+    if (fail) throw HipFailure((int)hipErrorOutOfMemory, "work-buffer reservation failed: out of memory (injected by the inject_alloc_failures test hook)");
   }
-  reserve_work(ctx, chunk_work_bytes(p, n, use_tables, sizeof(XyzzDev)));
+  reserve_work(ctx, chunk_work_bytes(p, n, use_tables, sizeof(XyzzDev), carry != nullptr));
   const uint32_t table_stride = use_tables ? (uint32_t)ctx->nbases : 0u;
-  const PartPlan gp = part_plan((uint32_t)n, p.c, p.windows, use_tables, (uint32_t)base0, table_stride);
+  const PartPlan gp = part_plan((uint32_t)n, p.c, p.windows, use_tables, (uint32_t)base0, table_stride, ctx->opt_assume_subgroup != 0);
   const size_t nbuckets = (size_t)p.bucket_windows * p.half;
   if (ctx->pinned_bytes < p.windows * sizeof(XyzzDev)) {
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
@@ -613,7 +649,7 @@ bool run_chunk_impl(mi355_msm_ctx* ctx, const uint32_t* d_scalars, size_t base0,
   uint32_t* flags = ctx->flags.as<uint32_t>();
 
   // digits + bucket grouping: (value, key) entries sorted by key in entries[sorted]; the count of real entries stays on the device
-  HIP_OK(hipEventRecord(ctx->ev[0], st));
+  HIP_OK(hipEventRecord(ev[0], st));
   PartBuffers gb{};
   gb.entries[0] = ctx->entries[0].as<uint2>();
   gb.entries[1] = ctx->entries[1].as<uint2>();
@@ -626,19 +662,19 @@ bool run_chunk_impl(mi355_msm_ctx* ctx, const uint32_t* d_scalars, size_t base0,
   gb.totals = ctx->part_totals.as<uint32_t>();
   hipError_t gerr = hipSuccess;
   const int sorted = PartLaunch::run(ctx->curve == MI355_BLS12_381_G1 ? 1 : 0, ctx->opt_scalars_montgomery != 0, d_scalars, inf, gp, gb, st,
-                                     ctx->ev[1], gerr);
+                                     ev[1], gerr);
   HIP_OK(gerr);
   const uint2* entries = gb.entries[sorted];
   const uint32_t* n_real = gb.totals;
   HIP_OK(hipMemsetAsync(ctx->buckets.p, 0, nbuckets * sizeof(XyzzDev), st));
-  HIP_OK(hipEventRecord(ctx->ev[2], st));
+  HIP_OK(hipEventRecord(ev[2], st));
 
   SegOut so{ctx->buckets.as<XyzzDev>(), ctx->slots[0].as<XyzzDev>(), ctx->slot_keys[0].as<uint32_t>()};
   if constexpr (TE)
     HIP_OK(LaunchTe::accumulate(entries, n_real, p.K, ctx->te_bases.as<TeAffineDev>(), so, p.nlanes, flags, st));
   else
     HIP_OK(Launch<E>::accumulate(entries, n_real, p.K, bases, so, p.nlanes, st));
-  HIP_OK(hipEventRecord(ctx->ev[3], st));
+  HIP_OK(hipEventRecord(ev[3], st));
 
   // merge the run fragments that crossed lane boundaries
   uint32_t n_in = 2 * p.nlanes;
@@ -657,7 +693,36 @@ bool run_chunk_impl(mi355_msm_ctx* ctx, const uint32_t* d_scalars, size_t base0,
       cur ^= 1;
     }
   }
-  HIP_OK(hipEventRecord(ctx->ev[4], st));
+  // carried buckets: the first chunk's array becomes the batch's, later chunks are added to it
+  XyzzDev* bucket_src = ctx->buckets.as<XyzzDev>();
+  if (carry) {
+    if (carry->first) {
+      std::swap(ctx->buckets, ctx->carry_buckets);
+    } else {
+      if constexpr (TE)
+        HIP_OK(LaunchTe::bucket_merge(ctx->carry_buckets.as<XyzzDev>(), ctx->buckets.as<XyzzDev>(), (uint32_t)nbuckets, flags, st));
+      else
+        HIP_OK(Launch<E>::bucket_merge(ctx->carry_buckets.as<XyzzDev>(), ctx->buckets.as<XyzzDev>(), (uint32_t)nbuckets, st));
+    }
+    bucket_src = ctx->carry_buckets.as<XyzzDev>();
+  }
+  HIP_OK(hipEventRecord(ev[4], st));
+  ctx->last_info[0] = p.c;
+  ctx->last_info[1] = p.windows;
+  ctx->last_info[6] = ctx->pre_c ? 1 : 0;
+  ctx->last_info[2] = NE;
+  ctx->last_info[3] = p.K;
+  ctx->last_info[4] += 1;
+  ctx->last_info[5] = p.nlanes;
+  ctx->last_info[7] = TE ? 1 : 0;
+  if (carry && !carry->last) {
+    // nothing to reduce yet, nothing to wait for: the next chunk's kernels queue up behind these
+    HIP_OK(hipEventRecord(ev[5], st));
+    HIP_OK(hipEventRecord(ev[6], st));
+    if (while_gpu_busy) (*while_gpu_busy)();
+    HostTail<E>::set_inf(out);
+    return true;
+  }
 
   // buckets -> one point per window
   const XyzzDev* sums_src = nullptr;   // where the W window sums end up: element 0 of rows that are sums_stride elements apart
@@ -666,14 +731,14 @@ bool run_chunk_impl(mi355_msm_ctx* ctx, const uint32_t* d_scalars, size_t base0,
     // parallel scan, one addition per thread and step.  Direct: on the buckets, ping-pong with a second bucket-sized array.
     // Otherwise: one chunked level first (A_t, X_t per chunk), scan on the X_t, join with the A_t, tree.
     uint32_t nb = p.half;
-    XyzzDev* bufs[2] = {ctx->buckets.as<XyzzDev>(), ctx->red_a[0].as<XyzzDev>()};
+    XyzzDev* bufs[2] = {bucket_src, ctx->red_a[0].as<XyzzDev>()};
     const XyzzDev* a_sums = nullptr;
     if (!p.scan_direct) {
       if constexpr (TE)
-        HIP_OK(LaunchTe::bucket_reduce(true, nullptr, ctx->buckets.as<XyzzDev>(), p.half, p.logL0, p.T0, p.bucket_windows,
+        HIP_OK(LaunchTe::bucket_reduce(true, nullptr, bucket_src, p.half, p.logL0, p.T0, p.bucket_windows,
                                        ctx->red_a[0].as<XyzzDev>(), ctx->red_x[0].as<XyzzDev>(), flags, st));
       else
-        HIP_OK(Launch<E>::bucket_reduce(true, nullptr, ctx->buckets.as<XyzzDev>(), p.half, p.logL0, p.T0, p.bucket_windows,
+        HIP_OK(Launch<E>::bucket_reduce(true, nullptr, bucket_src, p.half, p.logL0, p.T0, p.bucket_windows,
                                         ctx->red_a[0].as<XyzzDev>(), ctx->red_x[0].as<XyzzDev>(), st));
       nb = p.T0;
       a_sums = ctx->red_a[0].as<XyzzDev>();
@@ -693,7 +758,7 @@ bool run_chunk_impl(mi355_msm_ctx* ctx, const uint32_t* d_scalars, size_t base0,
     if (nb & (nb - 1)) bad_arg("scan reduction needs a power-of-two element count per window (%u)", nb);
     for (uint32_t h = nb >> 1; h >= 1; h >>= 1) step(h, 1);   // out_j = in_j + in_(j+h) for j < h
     if (nb == 1 && !a_sums) step(1, 0);   // a single bucket per window: one pass that normalises an empty bucket to the identity
-    HIP_OK(hipEventRecord(ctx->ev[5], st));
+    HIP_OK(hipEventRecord(ev[5], st));
     // the window sums sit at the head of each window's row
     sums_src = bufs[cur];
     sums_stride = nb;
@@ -701,10 +766,10 @@ bool run_chunk_impl(mi355_msm_ctx* ctx, const uint32_t* d_scalars, size_t base0,
     uint32_t n_per_win = p.half, logL = p.logL0, chunks = p.T0;
     int rb = 0;
     if constexpr (TE)
-      HIP_OK(LaunchTe::bucket_reduce(true, nullptr, ctx->buckets.as<XyzzDev>(), n_per_win, logL, chunks, p.bucket_windows,
+      HIP_OK(LaunchTe::bucket_reduce(true, nullptr, bucket_src, n_per_win, logL, chunks, p.bucket_windows,
                                      ctx->red_a[0].as<XyzzDev>(), ctx->red_x[0].as<XyzzDev>(), flags, st));
     else
-      HIP_OK(Launch<E>::bucket_reduce(true, nullptr, ctx->buckets.as<XyzzDev>(), n_per_win, logL, chunks, p.bucket_windows,
+      HIP_OK(Launch<E>::bucket_reduce(true, nullptr, bucket_src, n_per_win, logL, chunks, p.bucket_windows,
                                       ctx->red_a[0].as<XyzzDev>(), ctx->red_x[0].as<XyzzDev>(), st));
     while (chunks > 1) {
       n_per_win = chunks;
@@ -718,7 +783,7 @@ bool run_chunk_impl(mi355_msm_ctx* ctx, const uint32_t* d_scalars, size_t base0,
                                         p.bucket_windows, ctx->red_a[rb ^ 1].as<XyzzDev>(), ctx->red_x[rb ^ 1].as<XyzzDev>(), st));
       rb ^= 1;
     }
-    HIP_OK(hipEventRecord(ctx->ev[5], st));
+    HIP_OK(hipEventRecord(ev[5], st));
     sums_src = ctx->red_a[rb].as<XyzzDev>();
     sums_stride = 1;
   }
@@ -729,7 +794,7 @@ bool run_chunk_impl(mi355_msm_ctx* ctx, const uint32_t* d_scalars, size_t base0,
                        p.bucket_windows, reinterpret_cast<uint4*>(ctx->pinned), TE ? flags : nullptr, TE ? ctx->h_flags : nullptr);
     HIP_OK(hipGetLastError());
   }
-  HIP_OK(hipEventRecord(ctx->ev[6], st));
+  HIP_OK(hipEventRecord(ev[6], st));
   // everything for this chunk is enqueued: host work that should hide behind it (the next batch's H2D copy) goes here
   if (while_gpu_busy) (*while_gpu_busy)();
   // A small MSM is ~0.5 ms of device time and the blocking wait of the runtime wakes up in steps of ~0.15 ms (wall times of
@@ -737,7 +802,7 @@ bool run_chunk_impl(mi355_msm_ctx* ctx, const uint32_t* d_scalars, size_t base0,
   // then block as before.
   if (p.entries < (1ull << 26)) {
     const auto t_spin = std::chrono::steady_clock::now();
-    while (hipEventQuery(ctx->ev[6]) == hipErrorNotReady) {
+    while (hipEventQuery(ev[6]) == hipErrorNotReady) {
       if (std::chrono::steady_clock::now() - t_spin > std::chrono::milliseconds(4)) break;
     }
     (void)hipGetLastError();
@@ -756,47 +821,52 @@ bool run_chunk_impl(mi355_msm_ctx* ctx, const uint32_t* d_scalars, size_t base0,
     HostTail<E>::fold(out, sums.data(), (int)p.bucket_windows, (int)p.c);
   ctx->last_ms[MI355_T_HOST_FOLD] += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_fold).count();
 
-  float ms = 0;
-  for (int s = 0; s < 5; s++) {
-    HIP_OK(hipEventElapsedTime(&ms, ctx->ev[s], ctx->ev[s + 1]));
-    ctx->last_ms[s] += ms;
+  // stage times: of this chunk, or of every chunk of the carried batch (their events have all completed by now)
+  for (uint32_t k = carry ? 0 : 0, nk = carry ? carry->index + 1 : 1; k < nk; k++) {
+    hipEvent_t* const e = carry ? carry_events(ctx, k) : ctx->ev;
+    float ms = 0;
+    for (int s = 0; s < 5; s++) {
+      HIP_OK(hipEventElapsedTime(&ms, e[s], e[s + 1]));
+      ctx->last_ms[s] += ms;
+    }
+    HIP_OK(hipEventElapsedTime(&ms, e[0], e[6]));
+    ctx->last_ms[MI355_T_TOTAL] += ms;
   }
-  HIP_OK(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[6]));
-  ctx->last_ms[MI355_T_TOTAL] += ms;
-  ctx->last_info[0] = p.c;
-  ctx->last_info[1] = p.windows;
-  ctx->last_info[6] = ctx->pre_c ? 1 : 0;
-  ctx->last_info[2] = NE;
-  ctx->last_info[3] = p.K;
-  ctx->last_info[4] += 1;
-  ctx->last_info[5] = p.nlanes;
-  ctx->last_info[7] = TE ? 1 : 0;
   return ok;
 }
 
+// A base set that trips the incomplete law twice in a row (points outside the prime-order subgroup) would pay for both paths
+// on every call: demote the context to XYZZ for good and give the twisted-Edwards records back.
+void te_fell_back(mi355_msm_ctx* ctx) {
+  if (++ctx->te_fallback_streak >= 2) {
+    ctx->te_active = false;
+    ctx->te_demotions++;
+    ctx->te_bases.release();
+  }
+}
+
+// Returns false only for a chunk of a CARRIED batch whose twisted-Edwards run failed: the batch's buckets are Edwards sums then, so
+// the caller repeats the whole batch with allow_te = false (a lone chunk is repeated here, on the XYZZ path).
 template <class C>
-void run_chunk(mi355_msm_ctx* ctx, const uint32_t* d_scalars, size_t base0, size_t n, hipStream_t st,
-               typename HostTail<typename C::E>::Pt& out, const std::function<void()>* while_gpu_busy = nullptr) {
+bool run_chunk(mi355_msm_ctx* ctx, const uint32_t* d_scalars, size_t base0, size_t n, hipStream_t st,
+               typename HostTail<typename C::E>::Pt& out, const std::function<void()>* while_gpu_busy = nullptr,
+               const BucketCarry* carry = nullptr, bool allow_te = true) {
   if constexpr (std::is_same_v<C, Bls12_377_G1>) {
-    if (ctx->te_active) {
-      if (run_chunk_impl<C, true>(ctx, d_scalars, base0, n, st, out, while_gpu_busy)) {
-        ctx->te_fallback_streak = 0;
-        return;
+    if (ctx->te_active && allow_te) {
+      if (run_chunk_impl<C, true>(ctx, d_scalars, base0, n, st, out, while_gpu_busy, carry)) {
+        if (!carry || carry->last) ctx->te_fallback_streak = 0;
+        return true;
       }
       ctx->te_fallbacks++;
+      if (carry) return false;
       // (the hook -- the next batch's H2D copy -- has run already)
       run_chunk_impl<C, false>(ctx, d_scalars, base0, n, st, out, nullptr);
-      // A base set that trips the incomplete law twice in a row (points outside the prime-order subgroup) would pay for
-      // both paths on every call: demote the context to XYZZ for good and give the twisted-Edwards records back.
-      if (++ctx->te_fallback_streak >= 2) {
-        ctx->te_active = false;
-        ctx->te_demotions++;
-        ctx->te_bases.release();
-      }
-      return;
+      te_fell_back(ctx);
+      return true;
     }
   }
-  run_chunk_impl<C, false>(ctx, d_scalars, base0, n, st, out, while_gpu_busy);
+  run_chunk_impl<C, false>(ctx, d_scalars, base0, n, st, out, while_gpu_busy, carry);
+  return true;
 }
 
 // Streams the scalar batches of a host-pointer run: batch b+1 is copied while batch b computes
@@ -812,7 +882,7 @@ struct HostBatches {
   size_t host_batch_bytes;   // bytes between batches in the host buffer
   hipStream_t copy_stream;
   hipEvent_t ready[2];   // whole batch b resident: ready[b & 1]
-  hipEvent_t head;       // first piece of batch 0 resident
+  hipEvent_t piece[7];   // batch 0 arrives in up to eight pieces: piece i resident (the last piece signals ready[0])
   void copy_pairs(size_t b, size_t first, size_t count, hipEvent_t ev) const {
     HIP_OK(hipMemcpyAsync(dev + b * batch_bytes + first * 32, host + b * host_batch_bytes + first * 32, count * 32, hipMemcpyHostToDevice,
                           copy_stream));
@@ -821,11 +891,24 @@ struct HostBatches {
   void copy(size_t b) const { copy_pairs(b, 0, batch_bytes / 32, ready[b & 1]); }
 };
 
-// Pairs of the first batch that are copied (and computed) ahead of the rest; 0 = no split.  The extra chunk costs one more
-// bucket reduction (~5 ms at 2^26), so it only pays when the copy it hides is longer than that.
-inline size_t first_piece_pairs(size_t n, size_t max_chunk) {
-  if (n < ((size_t)1 << 23)) return 0;
-  return std::min(n / 4, max_chunk);
+// The first batch of a host-scalar run -- whose copy nothing can hide -- is handed over in pieces, each computed while the next one
+// crosses PCIe (CMB MSM.cu:419-434 splits its first copy 1/4 + 3/4; P1A matter-labs/src/lib.rs:171-182 grows its chunks).
+// PCIe delivers 2^26 scalars in ~37 ms and the device works through them in ~110 ms, so a piece can be three times its
+// predecessor: n/div, then x 3 each, the last piece taking what is left.  With carried buckets a piece costs one bucket merge
+// (~1.5 ms at 2^26), so three pieces pay: n/13, 3n/13, 9n/13 -- the device waits for 2.8 ms of copy instead of 9.4.  Without
+// (carry = 0) a piece costs a bucket reduction, a synchronisation and a host fold: 1/4 + 3/4 as before.
+// Returns the piece boundaries (front() = 0, back() = n); two entries = no split.
+inline std::vector<size_t> first_batch_pieces(size_t n, size_t max_chunk, size_t div) {
+  std::vector<size_t> pb{0};
+  if (n >= ((size_t)1 << 23) && div >= 2) {
+    size_t piece = std::min(n / div, max_chunk);
+    while (pb.size() < 7 && piece && pb.back() + piece + piece / 2 < n) {
+      pb.push_back(pb.back() + piece);
+      piece = std::min(piece * 3, max_chunk);
+    }
+  }
+  pb.push_back(n);
+  return pb;
 }
 
 // `dev_batch_pairs`: distance (in scalars) between two batches in the device buffer (n, or the total of a sharded run when a
@@ -841,60 +924,95 @@ void run_device_t(mi355_msm_ctx* ctx, uint8_t* out, const uint32_t* d_scalars, s
   size_t max_chunk = ctx->opt_max_chunk ? (size_t)ctx->opt_max_chunk : ((size_t)1 << 26);
   ctx->chunk_cap = 0;
   const size_t out_bytes = 3 * 4 * E::WORDS;
-  const size_t head = (hb && batches) ? first_piece_pairs(n, max_chunk) : 0;
-  if (hb && batches && n) {
-    if (head)
-      hb->copy_pairs(0, 0, head, hb->head);
-    else
-      hb->copy(0);
-  }
+  const size_t div = ctx->opt_first_piece_div ? (size_t)ctx->opt_first_piece_div : (ctx->opt_carry ? 13 : 4);
+  const std::vector<size_t> pb = (hb && batches) ? first_batch_pieces(n, max_chunk, div) : std::vector<size_t>{0, n};
+  const size_t P = pb.size() - 1;   // pieces of batch 0
+  size_t issued = 0;                // ... whose copy has been issued
+  std::vector<char> awaited(P, 0);
+  auto piece_event = [&](size_t i) { return i + 1 == P ? hb->ready[0] : hb->piece[i]; };
+  const std::function<void()> issue_next_piece = [&] {
+    hb->copy_pairs(0, pb[issued], pb[issued + 1] - pb[issued], piece_event(issued));
+    issued++;
+  };
+  if (hb && batches && n) issue_next_piece();
   for (size_t b = 0; b < batches; b++) {
     typename HostTail<E>::Pt total;
     HostTail<E>::set_inf(total);
-    const bool split = head && b == 0;
-    if (hb && n) HIP_OK(hipStreamWaitEvent(st, split ? hb->head : hb->ready[b & 1], 0));
-    bool rest_issued = !split, rest_awaited = !split, prefetched = false;
-    const std::function<void()> rest_of_first = [&] {
-      hb->copy_pairs(0, head, n - head, hb->ready[0]);
-      rest_issued = true;
-    };
+    const bool split = hb && b == 0 && P > 1;
+    if (hb && n) {
+      HIP_OK(hipStreamWaitEvent(st, b == 0 ? piece_event(0) : hb->ready[b & 1], 0));
+      if (b == 0) awaited[0] = 1;
+    }
+    bool prefetched = false;
     const std::function<void()> prefetch = [&] {
       if (hb && b + 1 < batches) hb->copy(b + 1);
       prefetched = true;
     };
+    // A batch that runs as several chunks carries one bucket array through them (BucketCarry): decided at its first chunk
+    BucketCarry carry{};
+    bool carried = false, allow_te = true;
     for (size_t off = 0; off < n;) {
       // plan the chunk against the memory that is there (ML msm.cu:453-466 plans first, too) ...
-      const bool tables_now = ctx->pre_c && (ctx->te_active || !ctx->sw_level0_only);
+      const bool tables_now = ctx->pre_c && ((ctx->te_active && allow_te) || !ctx->sw_level0_only);
       size_t cn = std::min(max_chunk, n - off);
-      if (split && off < head) cn = std::min(cn, head - off);
-      if (cn > ctx->fitted_chunk || tables_now != ctx->fitted_tables) cn = fit_chunk(ctx, cn, tables_now);
+      size_t piece = 0;   // the piece of batch 0 this chunk lies in: a chunk never crosses into a piece that may not have arrived
+      if (split) {
+        while (off >= pb[piece + 1]) piece++;
+        cn = std::min(cn, pb[piece + 1] - off);
+      }
+      auto fit = [&] {
+        const uint32_t fc = carried ? carry.c : 0;
+        if (cn > ctx->fitted_chunk || tables_now != ctx->fitted_tables || fc != ctx->fitted_c) cn = fit_chunk(ctx, cn, tables_now, fc);
+      };
+      fit();
+      if (off == 0 && !carried && cn < n && ctx->opt_carry) {
+        carried = true;
+        carry.c = ctx->plan(n, tables_now).c;   // the window size of the whole batch
+        carry.index = 0;
+        fit();                                  // ... under which a chunk needs other buffers
+      }
       const bool last = off + cn >= n;
-      if (split && !rest_awaited && off + cn > head) {
-        if (!rest_issued) rest_of_first();
-        HIP_OK(hipStreamWaitEvent(st, hb->ready[0], 0));
-        rest_awaited = true;
+      if (split && !awaited[piece]) {
+        while (issued <= piece) issue_next_piece();
+        HIP_OK(hipStreamWaitEvent(st, piece_event(piece), 0));
+        awaited[piece] = 1;
       }
       typename HostTail<E>::Pt part;
-      const std::function<void()>* hook = (!rest_issued) ? &rest_of_first : ((last && !prefetched) ? &prefetch : nullptr);
+      const std::function<void()>* hook = (split && issued < P) ? &issue_next_piece : ((last && !prefetched) ? &prefetch : nullptr);
+      carry.first = off == 0;
+      carry.last = last;
+      bool ok = true;
       try {
-        run_chunk<C>(ctx, d_scalars + (b * dev_batch_pairs + off) * 8, off, cn, st, part, hook);
+        ok = run_chunk<C>(ctx, d_scalars + (b * dev_batch_pairs + off) * 8, off, cn, st, part, hook, carried ? &carry : nullptr, allow_te);
       } catch (const HipFailure& e) {
         // ... and if an allocation fails all the same (fragmentation, another tenant), give the work buffers back and go on
-        // with half the chunk; results do not depend on the chunking
+        // with half the chunk; results do not depend on the chunking (the totals of a carried batch are kept)
         if (e.code != (int)hipErrorOutOfMemory || cn <= 1024) throw;
         (void)hipStreamSynchronize(st);
-        release_work_buffers(ctx);
+        release_work_buffers(ctx, carried && off > 0);
         max_chunk = ctx->chunk_cap = (cn + 1) / 2;   // for the rest of this run
         ctx->oom_backoffs++;
         continue;
       }
-      if (cn > ctx->fitted_chunk || tables_now != ctx->fitted_tables) {
+      if (!ok) {
+        // the twisted-Edwards run of a carried batch failed (flagged at its last chunk): the whole batch again, on the XYZZ path
+        allow_te = false;
+        off = 0;
+        carry.index = 0;
+        ctx->fitted_chunk = 0;
+        continue;
+      }
+      const uint32_t fc = carried ? carry.c : 0;
+      if (cn > ctx->fitted_chunk || tables_now != ctx->fitted_tables || fc != ctx->fitted_c) {
         ctx->fitted_chunk = cn;
         ctx->fitted_tables = tables_now;
+        ctx->fitted_c = fc;
       }
       HostTail<E>::add(total, part);
       off += cn;
+      carry.index++;
     }
+    if (!allow_te) te_fell_back(ctx);
     if (!prefetched) prefetch();   // n == 0
     const auto t0 = std::chrono::steady_clock::now();
     HostTail<E>::to_abi(out + b * out_bytes, total);
@@ -957,7 +1075,8 @@ void run_host(mi355_msm_ctx* ctx, void* out, const void* scalars, size_t n, size
     for (auto& ev : ctx->copy_ev) HIP_OK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
   }
   HostBatches hb{(const uint8_t*)scalars, ctx->scalars.as<uint8_t>(), n * 32, host_batch_pairs * 32, ctx->copy_stream,
-                 {ctx->copy_ev[0], ctx->copy_ev[1]}, ctx->copy_ev[2]};
+                 {ctx->copy_ev[0], ctx->copy_ev[1]}, {}};
+  for (int i = 0; i < 7; i++) hb.piece[i] = ctx->copy_ev[2 + i];
   try {
     run_device(ctx, out, ctx->scalars.p, n, batches, n, ctx->own_stream, &hb);
   } catch (...) {
@@ -1015,6 +1134,8 @@ RustError mi355_msm_destroy(mi355_msm_ctx* ctx) {
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->h_flags) (void)hipHostFree(ctx->h_flags);
     for (auto& ev : ctx->ev)
+      if (ev) (void)hipEventDestroy(ev);
+    for (auto& ev : ctx->carry_ev)
       if (ev) (void)hipEventDestroy(ev);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     for (auto& ev : ctx->copy_ev)
@@ -1186,6 +1307,13 @@ RustError mi355_msm_set_option(mi355_msm_ctx* ctx, const char* key, long value) 
       ctx->opt_precompute = value != 0;   // takes effect at the next set_bases
     } else if (k == "scalars_montgomery") {
       ctx->opt_scalars_montgomery = value != 0;
+    } else if (k == "assume_subgroup") {
+      ctx->opt_assume_subgroup = value != 0;
+    } else if (k == "carry") {
+      ctx->opt_carry = value != 0;
+    } else if (k == "first_piece_div") {
+      if (value != 0 && (value < 2 || value > 64)) bad_arg("first_piece_div %ld out of range [2, 64]", value);
+      ctx->opt_first_piece_div = value;
     } else if (k == "combine") {
       if (value < 0 || value > 2) bad_arg("combine %ld out of range [0, 2]", value);
       ctx->opt_combine = value;

@@ -440,6 +440,33 @@ __global__ void __launch_bounds__(256, G::ACC_WAVES) k_bucket_reduce(const XyzzD
 }
 
 // ------------------------------------------------------------------------------------------------
+// Carried buckets: a batch that runs as several chunks (the first piece of a host-scalar batch that is computed while the rest
+// crosses PCIe, the slices of the stateless pipeline, chunks sized to the free memory) keeps ONE bucket array for the batch and
+// reduces it once: total[b] += part[b] after every chunk but the first.  One full addition per bucket and chunk (6.8 M at c = 20)
+// instead of a bucket reduction (two per bucket, then the scan tail), a host fold and a stream synchronisation per chunk -- and
+// every chunk can use the window size of the WHOLE batch.
+template <class G>
+__global__ void __launch_bounds__(256, G::ACC_WAVES) k_bucket_merge(XyzzDevT<typename G::T>* __restrict__ total,
+                                                                    const XyzzDevT<typename G::T>* __restrict__ part, uint32_t n,
+                                                                    uint32_t* __restrict__ flags) {
+  using E = typename G::E;
+  using XD = XyzzDevT<typename G::T>;
+  const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+  if (g >= n) return;
+  const XD v = part[g];
+  if (G::nothing(v.p)) return;   // the chunk left this bucket empty
+  XD t = total[g];
+  if (G::nothing(t.p)) {
+    total[g] = v;
+    return;
+  }
+  typename E::Md md;
+  G::add(t.p, v.p, md);
+  if (G::CHECKS && G::failed(t.p)) flags[1] = 1;
+  total[g] = t;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Bucket -> window reduction for SMALL windows (<= 4096 buckets), as a parallel scan: the chunked running sums above are
 // work-efficient but ~80 full additions deep at 2^16 pairs, and a lone wave needs ~10 us per addition -- the bucket
 // reduction was 40 % of a small MSM.  Here every step is ONE addition per thread:

@@ -164,19 +164,28 @@ struct Uploader : msm_host::UploaderT<HipPipelineApi> {
 // Slice bounds: short first slices so that the first kernels start early (the growing chunks of P1A matter-labs/src/lib.rs:171-182).
 // ramp = 1: slice/8, slice/2, then full slices -- the compute side waits for 1/8 slice instead of 1/2 before its first kernel;
 // ramp = 0: slice/2, then full slices (the first version; kept for the A/B of profiles/r03_stateless_probe.txt).
-std::vector<size_t> stateless_slices(size_t n, size_t slice, int ramp) {
+// ramp_down (carried buckets only: a further slice then costs one merge, not a bucket reduction): the call ends with slices of
+// slice/2, slice/4, slice/8 -- what is left to compute when the last byte has crossed PCIe is an eighth of a slice and the one
+// bucket reduction, instead of a whole slice.
+std::vector<size_t> stateless_slices(size_t n, size_t slice, int ramp, bool ramp_down = false) {
   std::vector<size_t> lo{0};
-  if (n > slice + slice / 2) {
+  if (n == 0) return {0, 0};
+  std::vector<size_t> down;
+  if (ramp_down && slice >= 64 && n >= 4 * slice) down = {slice / 2, slice / 4, slice / 8};
+  size_t tail = 0;
+  for (size_t d : down) tail += d;
+  const size_t body = n - tail;   // what the ramp-up and the full slices cover
+  if (body > slice + slice / 2) {
     if (ramp && slice >= 64) lo.push_back(slice / 8);
     lo.push_back(lo.back() + slice / 2);
   }
-  while (lo.back() + slice < n) {
-    // do not leave a sliver for the last slice: it would pay a whole bucket reduction for a few pairs
-    if (n - (lo.back() + slice) < slice / 4) break;
+  while (lo.back() + slice < body) {
+    // do not leave a sliver for the last slice: it would pay a whole bucket reduction (or merge) for a few pairs
+    if (body - (lo.back() + slice) < slice / 4) break;
     lo.push_back(lo.back() + slice);
   }
-  lo.push_back(n);
-  if (n == 0) lo = {0, 0};
+  lo.push_back(body);
+  for (size_t d : down) lo.push_back(lo.back() + d);
   return lo;
 }
 
@@ -203,11 +212,17 @@ void stateless_t(mi355_msm_ctx* ctx, uint8_t* out, const uint8_t* affine, size_t
     // overlap) and 2^23 (1.1 GB: 20 ms of PCIe against ~20 ms of compute)
     const long auto_log = std::min<long>(23, std::max<long>(20, (long)ilog2_floor(std::max<size_t>(n, 4) / 4)));
     const size_t slice = (size_t)1 << env_long("MI355_MSM_STATELESS_SLICE_LOG", auto_log, 10, 26);
-    const std::vector<size_t> lo = stateless_slices(n, slice, (int)env_long("MI355_MSM_STATELESS_RAMP", 1, 0, 1));
+    const bool want_carry = ctx->opt_carry && env_long("MI355_MSM_STATELESS_CARRY", 0, 0, 1);
+    const std::vector<size_t> lo = stateless_slices(n, slice, (int)env_long("MI355_MSM_STATELESS_RAMP", 1, 0, 1),
+                                                    env_long("MI355_MSM_STATELESS_RAMP_DOWN", 0, 0, 1) != 0);
     const uint32_t S = (uint32_t)lo.size() - 1;
     size_t max_cnt = 0;
     for (uint32_t s = 0; s < S; s++) max_cnt = std::max(max_cnt, lo[s + 1] - lo[s]);
 
+    // the slices share one bucket array (BucketCarry, msm_engine.hip): every slice groups and accumulates with the window size of
+    // the whole call, only the last one reduces; 0 = every slice reduces its own buckets with its own window size
+    const uint32_t carry_c = (S > 1 && want_carry) ? ctx->plan(n, false).c : 0;
+    BucketCarry carry{carry_c, 0, true, false};
     const bool trace = env_long("MI355_MSM_STATELESS_TRACE", 0, 0, 1) != 0;   // per-slice timeline on stderr
     std::vector<double> tr_ready(S), tr_done(S);
     std::vector<std::pair<const char*, double>> tr_setup;
@@ -233,10 +248,10 @@ void stateless_t(mi355_msm_ctx* ctx, uint8_t* out, const uint8_t* affine, size_t
         bool fits = true;
         for (uint32_t s = 0; s < S; s++) {
           const size_t cnt = lo[s + 1] - lo[s];
-          if (s > 2 && s + 1 < S) continue;   // the slices in between have the size of slice 2
-          const Plan p = ctx->plan(cnt, false);
+          if (s > 2 && s + 4 < S) continue;   // the slices in between have the size of slice 2
+          const Plan p = ctx->plan(cnt, false, carry_c);
           fits = fits && p.entries < (1ull << 32);
-          w.max_with(chunk_work_bytes(p, cnt, false, sizeof(XyzzDevT<typename E::T>)));
+          w.max_with(chunk_work_bytes(p, cnt, false, sizeof(XyzzDevT<typename E::T>), carry_c != 0));
         }
         if (fits && !ctx->opt_mem_limit) {
           try {
@@ -302,14 +317,15 @@ void stateless_t(mi355_msm_ctx* ctx, uint8_t* out, const uint8_t* affine, size_t
         size_t max_chunk = ctx->opt_max_chunk ? (size_t)ctx->opt_max_chunk : ((size_t)1 << 26);
         for (size_t off = 0; off < cnt;) {
           size_t cn = std::min(max_chunk, cnt - off);
-          if (cn > ctx->fitted_chunk) cn = fit_chunk(ctx, cn, false);
+          if (cn > ctx->fitted_chunk) cn = fit_chunk(ctx, cn, false, carry_c);
           typename HostTail<E>::Pt part;
+          carry.last = s + 1 == S && off + cn >= cnt;
           try {
-            run_chunk<C>(ctx, ctx->scalars.as<uint32_t>() + (lo[s] + off) * 8, off, cn, st, part, nullptr);
+            run_chunk<C>(ctx, ctx->scalars.as<uint32_t>() + (lo[s] + off) * 8, off, cn, st, part, nullptr, carry_c ? &carry : nullptr);
           } catch (const HipFailure& e) {
             if (e.code != (int)hipErrorOutOfMemory || cn <= 1024) throw;
             (void)hipStreamSynchronize(st);
-            release_work_buffers(ctx);
+            release_work_buffers(ctx, carry_c && !carry.first);   // (the totals of the slices so far stay)
             max_chunk = ctx->chunk_cap = (cn + 1) / 2;
             ctx->oom_backoffs++;
             continue;
@@ -317,6 +333,8 @@ void stateless_t(mi355_msm_ctx* ctx, uint8_t* out, const uint8_t* affine, size_t
           if (cn > ctx->fitted_chunk) ctx->fitted_chunk = cn;
           HostTail<E>::add(total, part);
           off += cn;
+          carry.first = false;
+          carry.index++;
         }
         const double c_ms = ms_since(t_comp);
         tr_done[s] = ms_since(t_begin);

@@ -11,7 +11,7 @@
 //                      written as one row of a [tiles x bins] matrix (no atomics: deterministic offsets)
 //        k_l1_scan_*   column scan of the matrix -> the offset of every (tile, bin) run, the bin (= segment) table
 //        k_l1_scatter  digits again (cheaper than keeping 7 GB of them), LDS multisplit of the tile's 8192 entries of one
-//                      window into its 512 bins, flushed as ~16-entry / 128-B contiguous runs of u64 entries
+//                      window into its 512 or 1024 bins, flushed as ~16- or ~8-entry (128- / 64-B) contiguous runs of u64 entries
 //                      (value = base index | sign << 31 in the low word, remaining bucket bits in the high word)
 //   Pn   one or more generic passes over the segments the previous level produced, RB more bucket bits each:
 //        k_pass_hist / k_pass_scan / k_pass_scatter -- a segment is cut into sub-jobs of <= SUBJOB entries, one block each, so
@@ -72,14 +72,57 @@ struct ScalarDigits {
   uint32_t carry;
 };
 // Next signed digit (CMB ProcessSignedDigits.cu:118-151 semantics): |d| in [0, 2^(c-1)], neg = the digit is negative.
-__device__ __forceinline__ void next_digit(ScalarDigits& st, uint32_t c, uint32_t half, uint32_t wmask, uint32_t& mag, bool& neg) {
-  const uint32_t v = (st.s[0] & wmask) + st.carry;
+// `flip` (the context option assume_subgroup): the top-bit trick of the ZPrize winners (CMB ProcessSignedDigits.cu:10-20,123-128:
+// "if bit 252 of k is set use k' = r - k and -P"), here for every k in (r/2, r): k P = (r - k)(-P) whenever r P = O, and r - k has
+// one significant bit less -- 252 = 12 x 21 bits for BLS12-377, so the window above them only ever receives the last carry (14.5 %
+// of the scalars instead of 57 %).  r - k is never formed: its windows are rwin - (window of k) - borrow, with `rwin` the same
+// window of r (wave-uniform: scalar registers), the borrow in bit 1 of `carry` -- the level-1 scatter holds eight scalars per
+// thread in a 128-VGPR budget, and neither a pass over them nor a ninth register per scalar fits (both spilled).
+// FOLD = false (the default path) compiles to the plain recoding: the option costs nothing when it is off.
+template <bool FOLD>
+__device__ __forceinline__ void next_digit(ScalarDigits& st, uint32_t c, uint32_t half, uint32_t wmask, bool flip, uint32_t rwin, uint32_t& mag,
+                                           bool& neg) {
+  uint32_t u = st.s[0] & wmask;
 #pragma unroll
   for (int j = 0; j < 7; j++) st.s[j] = (st.s[j] >> c) | (st.s[j + 1] << (32 - c));
   st.s[7] >>= c;
-  neg = v > half;
-  mag = neg ? (1u << c) - v : v;
-  st.carry = neg ? 1u : 0u;
+  if constexpr (FOLD) {
+    const uint32_t sub = u + ((st.carry >> 1) & 1u);   // <= 2^c
+    const bool borrow = flip && rwin < sub;
+    u = flip ? ((rwin - sub) & wmask) : u;
+    const uint32_t v = u + (st.carry & 1u);
+    const bool over = v > half;
+    mag = over ? (1u << c) - v : v;
+    neg = over != flip;
+    st.carry = (over ? 1u : 0u) | (borrow ? 2u : 0u);
+  } else {
+    const uint32_t v = u + st.carry;
+    neg = v > half;
+    mag = neg ? (1u << c) - v : v;
+    st.carry = neg ? 1u : 0u;
+  }
+}
+
+// window w of the scalar-field modulus (w, c wave-uniform)
+template <class FR>
+__device__ __forceinline__ uint32_t fr_window(uint32_t w, uint32_t c, uint32_t wmask) {
+  const uint32_t o = w * c, limb = o >> 5, sh = o & 31;
+  if (limb >= 8) return 0;
+  uint32_t lo = 0, hi = 0;
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    if ((uint32_t)j == limb) lo = FR::R[j];
+    if ((uint32_t)j == limb + 1) hi = FR::R[j];
+  }
+  return ((lo >> sh) | (sh ? hi << (32 - sh) : 0u)) & wmask;
+}
+
+// Folded or not, on the top limb alone: top(r)/2 < top(k) < top(r) implies r/2 < k < r; the 3e-9 of the scalars whose top limb
+// EQUALS one of the bounds stay as they are, which is just as correct (folding is a per-scalar choice) and only means that their
+// last carry may reach the window above.  Scalars >= r are left alone (any 256-bit integer stays legal).
+template <class FR>
+__device__ __forceinline__ bool fold_decision(const ScalarDigits& st) {
+  return st.s[7] > (FR::R[7] >> 1) && st.s[7] < FR::R[7];
 }
 
 template <class FR, bool MONT>
@@ -136,7 +179,7 @@ __device__ __forceinline__ uint32_t l1_bin(const PartPlan& p, uint32_t w, uint32
 
 // ------------------------------------------------------------------------------------------------------------------------
 // L1 histogram: one block per tile, matrix row = the tile's entry count per level-1 bin.
-template <class FR, bool MONT>
+template <class FR, bool MONT, bool FOLD>
 __global__ void __launch_bounds__(PART_THREADS) k_l1_hist(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ inf, PartPlan p,
                                                           uint32_t* __restrict__ matrix) {
   extern __shared__ uint32_t hist[];   // nbins
@@ -155,8 +198,10 @@ __global__ void __launch_bounds__(PART_THREADS) k_l1_hist(const uint32_t* __rest
     if (i0 + k * PART_THREADS >= p.n) break;   // (block-uniform) the tile ends here: a 1024-scalar MSM has one live slot of eight
     if (!few && !have) break;
     ScalarDigits st;
+    bool flip = false;
     if (have) {
       load_scalar<FR, MONT>(st, scalars, i);
+      if (FOLD) flip = fold_decision<FR>(st);
     } else {
 #pragma unroll
       for (int j = 0; j < 8; j++) st.s[j] = 0;
@@ -166,7 +211,7 @@ __global__ void __launch_bounds__(PART_THREADS) k_l1_hist(const uint32_t* __rest
     for (uint32_t w = 0; w < p.windows; w++) {
       uint32_t mag;
       bool neg;
-      next_digit(st, p.c, p.half, wmask, mag, neg);
+      next_digit<FOLD>(st, p.c, p.half, wmask, flip, FOLD ? fr_window<FR>(w, p.c, wmask) : 0u, mag, neg);
       if (w < w_lo || w >= w_hi) continue;   // (block-uniform) another block of this tile counts that window
       bool dead = dead0;
       if (have && p.table_stride) dead = inf[p.idx0 + i + w * p.table_stride] != 0;
@@ -282,7 +327,7 @@ __global__ void __launch_bounds__(256) k_l1_scan_c(uint32_t* __restrict__ matrix
 // With shared buckets the segments of the next pass are the b1 bucket ranges, each the union of `windows` neighbouring bins.
 __global__ void __launch_bounds__(256) k_l1_merge_shared(const PartSeg* __restrict__ bins, PartPlan p, PartSeg* __restrict__ segs,
                                                          uint32_t* __restrict__ subjob_first, uint32_t* __restrict__ totals) {
-  // one block; b1 <= 512 segments
+  // one block; b1 <= 1024 segments
   __shared__ uint32_t tmp[32];
   for (uint32_t h0 = 0; h0 < p.b1; h0 += 256) {
     const uint32_t h = h0 + threadIdx.x;
@@ -308,7 +353,7 @@ __global__ void __launch_bounds__(256) k_l1_merge_shared(const PartSeg* __restri
 
 // L1 scatter: one block per tile; the tile's scalars stay in registers while the windows are processed one after the other.
 // LDS: stage (8192 x u64; the bin rides in the high half of the key word until the entry leaves) + three (b1 + 1)-word arrays.
-template <class FR, bool MONT>
+template <class FR, bool MONT, bool FOLD>
 __global__ void __launch_bounds__(PART_THREADS) k_l1_scatter(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ inf, PartPlan p,
                                                              const uint32_t* __restrict__ matrix, uint2* __restrict__ out) {
   __shared__ uint2 stage[PART_TILE];
@@ -324,7 +369,7 @@ __global__ void __launch_bounds__(PART_THREADS) k_l1_scatter(const uint32_t* __r
   // for seven empty slots were 3/4 of this kernel's time on a 1024-scalar MSM
   const uint32_t kmax = min((uint32_t)PART_PER_THREAD, (p.n - i0 + PART_THREADS - 1) / PART_THREADS);
   ScalarDigits st[PART_PER_THREAD];
-  uint32_t alive = 0;     // bit k: scalar k exists and (without tables) its base is not flagged infinite
+  uint32_t alive = 0;     // bit k: scalar k exists and (without tables) its base is not flagged infinite; bit 8 + k: scalar k was folded
 #pragma unroll
   for (int k = 0; k < PART_PER_THREAD; k++) {
     const uint32_t i = i0 + threadIdx.x + k * PART_THREADS;
@@ -337,6 +382,11 @@ __global__ void __launch_bounds__(PART_THREADS) k_l1_scatter(const uint32_t* __r
       st[k].carry = 0;
     }
   }
+  if (FOLD) {
+#pragma unroll
+    for (int k = 0; k < PART_PER_THREAD; k++)
+      if (fold_decision<FR>(st[k])) alive |= 0x100u << k;   // (an all-zero slot past the end is never folded)
+  }
   const uint32_t* row = matrix + (size_t)tile * p.nbins;
   // the run offsets of the next window are fetched a whole window step ahead (a global load in the step's critical path
   // would cost ~1.5 us of the ~10 us a step takes)
@@ -347,7 +397,7 @@ __global__ void __launch_bounds__(PART_THREADS) k_l1_scatter(const uint32_t* __r
       for (uint32_t w = 0; w < w_lo; w++) {
         uint32_t mag;
         bool neg;
-        next_digit(st[k], p.c, p.half, wmask, mag, neg);
+        next_digit<FOLD>(st[k], p.c, p.half, wmask, ((alive >> (8 + k)) & 1) != 0, FOLD ? fr_window<FR>(w, p.c, wmask) : 0u, mag, neg);
       }
     }
   }
@@ -360,7 +410,10 @@ __global__ void __launch_bounds__(PART_THREADS) k_l1_scatter(const uint32_t* __r
     }
     __syncthreads();
     uint32_t where[PART_PER_THREAD];   // bin << 16 | rank in the tile's bin; 0xffffffff = no entry
-    uint2 ent[PART_PER_THREAD];
+    uint32_t low[PART_PER_THREAD];     // the bucket bits below the bin | sign << 31 (the entry's base index is recomputed when it is staged:
+                                       // two registers per entry, not three -- this kernel runs at the 128-VGPR limit of a 1024-thread block;
+                                       // same speed as three, same-box A/B)
+    const uint32_t rwin = FOLD ? fr_window<FR>(w, p.c, wmask) : 0u;
 #pragma unroll
     for (int k = 0; k < PART_PER_THREAD; k++) {
       if ((uint32_t)k >= kmax) {
@@ -369,7 +422,7 @@ __global__ void __launch_bounds__(PART_THREADS) k_l1_scatter(const uint32_t* __r
       }
       uint32_t mag;
       bool neg;
-      next_digit(st[k], p.c, p.half, wmask, mag, neg);
+      next_digit<FOLD>(st[k], p.c, p.half, wmask, ((alive >> (8 + k)) & 1) != 0, rwin, mag, neg);
       const uint32_t i = i0 + threadIdx.x + k * PART_THREADS;
       bool ok = ((alive >> k) & 1) && mag != 0;
       const uint32_t idx = p.idx0 + i + w * p.table_stride;
@@ -383,12 +436,12 @@ __global__ void __launch_bounds__(PART_THREADS) k_l1_scatter(const uint32_t* __r
         rank = atomicAdd(&cnt[hi], 1u);
       if (ok) {
         where[k] = (hi << 16) | rank;
-        ent[k] = make_uint2(idx | (neg ? 0x80000000u : 0u), (bucket & lowmask) | (hi << 16));   // lb <= 15
+        low[k] = (bucket & lowmask) | (neg ? 0x80000000u : 0u);   // lb <= 15
       }
     }
     __syncthreads();
     {
-      // exclusive scan of the tile's bin counts (b1 <= 512 <= blockDim)
+      // exclusive scan of the tile's bin counts (b1 <= 1024 = blockDim)
       const uint32_t v = threadIdx.x < p.b1 ? cnt[threadIdx.x] : 0;
       uint32_t tot;
       const uint32_t ex = block_excl_scan(v, tmp, tot);
@@ -398,7 +451,11 @@ __global__ void __launch_bounds__(PART_THREADS) k_l1_scatter(const uint32_t* __r
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < PART_PER_THREAD; k++)
-      if (where[k] != 0xffffffffu) stage[tstart[where[k] >> 16] + (where[k] & 0xffffu)] = ent[k];
+      if (where[k] != 0xffffffffu) {
+        const uint32_t idx = p.idx0 + i0 + threadIdx.x + k * PART_THREADS + w * p.table_stride;
+        // (value = base index | sign << 31; key word while staged: the bits still unresolved with the bin above them)
+        stage[tstart[where[k] >> 16] + (where[k] & 0xffffu)] = make_uint2(idx | (low[k] & 0x80000000u), (low[k] & 0xffffu) | (where[k] & 0xffff0000u));
+      }
     __syncthreads();
     const uint32_t total = tstart[p.b1];
     for (uint32_t j = threadIdx.x; j < total; j += PART_THREADS) {
@@ -586,7 +643,10 @@ inline int part_run(const uint32_t* d_scalars, const uint8_t* d_inf, const PartP
   const uint64_t entries = (uint64_t)p.n * p.windows;
   const dim3 scan_grid(part_ceil_div(p.nbins, 256), PART_SCAN_GROUPS);
   const uint32_t l1_grid = 8 * ((p.ntiles + 7) / 8) * p.wgroups;   // l1_tile(): a contiguous tile range per XCD; wgroups blocks per tile
-  hipLaunchKernelGGL((k_l1_hist<FR, MONT>), dim3(l1_grid), dim3(PART_THREADS), p.nbins * 4, st, d_scalars, d_inf, p, b.matrix);
+  if (p.fold)
+    hipLaunchKernelGGL((k_l1_hist<FR, MONT, true>), dim3(l1_grid), dim3(PART_THREADS), p.nbins * 4, st, d_scalars, d_inf, p, b.matrix);
+  else
+    hipLaunchKernelGGL((k_l1_hist<FR, MONT, false>), dim3(l1_grid), dim3(PART_THREADS), p.nbins * 4, st, d_scalars, d_inf, p, b.matrix);
   hipLaunchKernelGGL(k_l1_scan_a, scan_grid, dim3(256), 0, st, b.matrix, p, b.partial);
   hipLaunchKernelGGL(k_l1_scan_b, dim3(1), dim3(1024), 0, st, b.partial, p, b.segs[0], b.subjob_first, b.totals);
   hipLaunchKernelGGL(k_l1_scan_c, scan_grid, dim3(256), 0, st, b.matrix, p, b.partial);
@@ -597,7 +657,10 @@ inline int part_run(const uint32_t* d_scalars, const uint8_t* d_inf, const PartP
     seg_cur = 1;
     nsegs = p.b1;
   }
-  hipLaunchKernelGGL((k_l1_scatter<FR, MONT>), dim3(l1_grid), dim3(PART_THREADS), 0, st, d_scalars, d_inf, p, b.matrix, b.entries[0]);
+  if (p.fold)
+    hipLaunchKernelGGL((k_l1_scatter<FR, MONT, true>), dim3(l1_grid), dim3(PART_THREADS), 0, st, d_scalars, d_inf, p, b.matrix, b.entries[0]);
+  else
+    hipLaunchKernelGGL((k_l1_scatter<FR, MONT, false>), dim3(l1_grid), dim3(PART_THREADS), 0, st, d_scalars, d_inf, p, b.matrix, b.entries[0]);
   if (mid) (void)hipEventRecord(mid, st);
   uint32_t rb[4];
   const int np = part_pass_bits(p.lb, rb);

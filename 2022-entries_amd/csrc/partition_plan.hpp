@@ -12,7 +12,12 @@ namespace msm {
 constexpr int PART_TILE = 8192;        // scalars per level-1 tile (8 per thread of a 1024-thread block)
 constexpr int PART_THREADS = 1024;
 constexpr int PART_PER_THREAD = PART_TILE / PART_THREADS;
-constexpr int PART_MAX_HB = 9;         // level-1 bins per window: 2^HB <= 512
+// 10 bits at level 1 (from 2^25 scalars on, see by_size below) leave c = 21 with ONE generic pass instead of two (sort 12.0 -> 6.8 ms
+// at 2^26) and c = 20 with a 9-bit one (sort 6.7 -> 5.8, level 1 4.4 -> 4.9: -0.3 ms); tools/ab_fold.sh, profiles/r03_ab_fold.txt
+#ifndef PART_MAX_HB_V
+#define PART_MAX_HB_V 10
+#endif
+constexpr int PART_MAX_HB = PART_MAX_HB_V;   // level-1 bins per window: 2^HB <= 1024 = the block size of the level-1 kernels
 constexpr int PART_MAX_RB = 10;        // bins of one generic pass: 2^RB <= 1024
 constexpr uint32_t PART_SUBJOB = 192u << 10;   // entries per sub-job of a generic pass
 #ifndef PART_PTILE_V
@@ -43,6 +48,7 @@ struct PartPlan {
   uint32_t ntiles;                   // ceil(n / PART_TILE)
   uint32_t tiles_per_group;          // column-scan grouping
   uint32_t wgroups, wper;            // level-1 blocks per tile (each takes `wper` consecutive windows): fills the chip when tiles are few
+  uint32_t fold;                     // 1: a scalar k in (r/2, r) is replaced by r - k with all its digits negated (load_scalar)
 };
 
 // Geometry of one generic pass.
@@ -57,8 +63,9 @@ struct PassPlan {
 inline uint32_t part_ceil_div(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
 
 // `shared` = all windows feed one bucket set (precomputed tables).
-inline PartPlan part_plan(uint32_t n, uint32_t c, uint32_t windows, bool shared, uint32_t idx0, uint32_t table_stride) {
+inline PartPlan part_plan(uint32_t n, uint32_t c, uint32_t windows, bool shared, uint32_t idx0, uint32_t table_stride, bool fold = false) {
   PartPlan p{};
+  p.fold = fold ? 1 : 0;
   p.n = n;
   p.c = c;
   p.windows = windows;

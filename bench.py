@@ -119,6 +119,8 @@ def main():
                     help="collective backend for --gpus > 1 (nccl = RCCL over xGMI; gloo only to rehearse the multi-rank path on one GPU)")
     ap.add_argument("--window-bits", type=int, default=0)
     ap.add_argument("--lane-entries", type=int, default=0)
+    ap.add_argument("--assume-subgroup", type=int, default=0,
+                    help="1 = context option assume_subgroup (scalars above r/2 run as (r - k)(-P): the winners' top-bit trick, valid for bases in the r-torsion)")
     args = ap.parse_args()
 
     import numpy as np
@@ -182,6 +184,8 @@ def main():
         ctx.set_option("window_bits", args.window_bits)
     if args.precompute:
         ctx.set_option("precompute", 1)
+    if args.assume_subgroup:
+        ctx.set_option("assume_subgroup", 1)
     t_init = time.perf_counter()
     ctx.set_bases(bases)
     torch.cuda.synchronize()

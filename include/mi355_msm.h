@@ -123,7 +123,17 @@ RustError mi355_msm_run_device(mi355_msm_ctx* ctx, void* out_projective, const v
  * "reduce_scan_log" 6..18 = log2 of the elements per window at which the scan takes over (default 12).
  * "quad_limit" (per context, default 2^18): merge / scan launches of at most that many additions spread each
  * addition over four lanes (latency); 0 = always one lane per addition.
- * Test hooks: "mem_limit" (bytes of device memory chunks may be planned against), "inject_alloc_failures".
+ * "assume_subgroup" = 1 (default 0): the caller guarantees that every base lies in the order-r subgroup (r P = O), as the ZPrize
+ * generator's do.  A scalar k in (r/2, r) then runs as (r - k)(-P): the winners' top-bit trick (CMB ProcessSignedDigits.cu:10-20,
+ * 123-128), one significant bit less, so BLS12-377 scalars tile 12 windows of 21 bits and the auto window size moves from 20 to 21
+ * at 2^26 pairs (-5 % additions).  Off by default because arkworks' msm is exact for ANY curve point and this is not.
+ * "carry" (default 1): a batch that runs as several chunks (max_chunk, the memory budget, the pieces of a host-scalar batch) carries
+ * ONE bucket array through them -- every chunk uses the window size of the whole batch and only the last one reduces; 0 = every
+ * chunk reduces its own buckets and the partial sums are added on the host.  "first_piece_div" (default 13; 4 with carry = 0): the
+ * first batch of a host-scalar run is handed over as pieces of n/div, 3n/div, 9n/div ... each computed while the next crosses PCIe
+ * (CMB MSM.cu:419-434 splits its first copy 1/4 + 3/4).
+ * Test hooks: "mem_limit" (bytes of device memory chunks may be planned against), "inject_alloc_failures" (N > 0: the next N
+ * work-buffer reservations fail; -K: only the K-th from now).
  * "scalars_montgomery" = 1 makes every run treat the scalars as arkworks `Fr` values (Montgomery form, a*2^256 mod r)
  * and convert them on the device first -- VariableBaseMSM::msm(bases, &[Fr]) = into_bigint + msm_bigint
  * (ARK ec/src/msm/variable_base/mod.rs:48-53; sppark's `mont` flag SPK msm/pippenger.cuh:157-164).
