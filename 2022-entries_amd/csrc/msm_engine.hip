@@ -1155,7 +1155,7 @@ RustError mi355_msm_create_sharded(mi355_msm_ctx** out, int curve, const int* de
   });
 }
 
-RustError mi355_msm_create_env(mi355_msm_ctx** out, int curve) {
+static RustError create_env_devices(mi355_msm_ctx** out, int curve) {
   // MI355_MSM_DEVICES = "0,1,2,3" | "all" | unset: a harness that never heard of more than one GPU picks them up here
   const char* env = getenv("MI355_MSM_DEVICES");
   if (!env || !*env) return mi355_msm_create(out, curve, -1);
@@ -1168,6 +1168,22 @@ RustError mi355_msm_create_env(mi355_msm_ctx** out, int curve) {
   }
   if (devs.size() == 1) return mi355_msm_create(out, curve, devs[0]);
   return mi355_msm_create_sharded(out, curve, devs.data(), (int)devs.size());
+}
+
+RustError mi355_msm_create_env(mi355_msm_ctx** out, int curve) {
+  RustError e = create_env_devices(out, curve);
+  if (e.code || !out || !*out) return e;
+  // MI355_MSM_ASSUME_SUBGROUP = 0 | 1: the harness's bases are (are not) all in the order-r subgroup -- option "assume_subgroup"
+  const char* sub = getenv("MI355_MSM_ASSUME_SUBGROUP");
+  if (sub && *sub) {
+    e = mi355_msm_set_option(*out, "assume_subgroup", atol(sub) != 0);
+    if (e.code) {
+      RustError d = mi355_msm_destroy(*out);
+      if (d.message) free(d.message);
+      *out = nullptr;
+    }
+  }
+  return e;
 }
 
 RustError mi355_msm_set_bases(mi355_msm_ctx* ctx, const void* affine, size_t npoints, size_t stride) {

@@ -28,6 +28,10 @@ void* MSMAllocContext(int32_t maxPoints, int32_t maxBatches) {
   yrrid_ctx* y = (yrrid_ctx*)calloc(1, sizeof *y);
   if (!y) return NULL;
   take(y, mi355_msm_create_env(&y->ctx, MI355_BLS12_377_G1));
+  /* The reference this shim stands in for negates every scalar with its top bit set (k' = r - k, -P: CMB ProcessSignedDigits.cu:
+   * 10-20,123-128), i.e. it relies on bases of order r; so does this context unless MI355_MSM_ASSUME_SUBGROUP says otherwise. */
+  const char* sub = getenv("MI355_MSM_ASSUME_SUBGROUP");
+  if (y->ctx && !(sub && *sub)) take(y, mi355_msm_set_option(y->ctx, "assume_subgroup", 1));
   return y;
 }
 

@@ -380,6 +380,16 @@ def main():
                     extras["xyzz_accumulate_ms"] = cx.last_timings()["accumulate"]
                     extras["xyzz_same_result"] = rx == result
                     cx.close()
+                if True:
+                    # the winners' top-bit trick as a context option (off by default: it needs every base in the order-r subgroup, which
+                    # this generator's bases are): scalars above r/2 run as (r - k)(-P), CMB ProcessSignedDigits.cu:123-128
+                    ctx.set_option("assume_subgroup", 1)
+                    ms_f, rf = timed(lambda: ctx.run(scalars)[0], args.steps)
+                    tf = ctx.last_timings()
+                    extras["assume_subgroup"] = {"ms_per_step": ms_f, "window_bits": tf["window_bits"], "accumulate_ms": tf["accumulate"] ,
+                                                 "same_result": rf == result,
+                                                 "what": "same workload with the context option assume_subgroup = 1 (not the headline: the default path is exact for any curve point)"}
+                    ctx.set_option("assume_subgroup", 0)
                 # one stateless call: host bases -> upload -> conversion (+ twisted-Edwards image) -> MSM -> teardown
                 # (a pipeline since round 3: slices cross PCIe through a pinned ring while earlier ones compute, csrc/msm_stateless.hpp)
                 bases_host = np.ascontiguousarray(np.tile(base_tile, (n // distinct, 1)))

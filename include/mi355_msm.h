@@ -86,7 +86,9 @@ RustError mi355_msm_destroy(mi355_msm_ctx* ctx);
  * Queries: "shards", "rccl_exchanges"; counters of the single-device queries add up over the shards. */
 RustError mi355_msm_create_sharded(mi355_msm_ctx** out, int curve, const int* devices, int ndevices);
 /* What the harness shims call: MI355_MSM_DEVICES = "0,1,2,3" | "0-7" | "all" selects a sharded context over those devices,
- * one entry (or unset) an ordinary one.  mi355_msm() (stateless) goes through here as well. */
+ * one entry (or unset) an ordinary one.  mi355_msm() (stateless) goes through here as well.
+ * MI355_MSM_ASSUME_SUBGROUP = 0 | 1 sets the option "assume_subgroup" on the new context (the yrrid shim turns it on unless this says 0:
+ * the reference it stands in for folds scalars with the top bit set, CMB ProcessSignedDigits.cu:123-128). */
 RustError mi355_msm_create_env(mi355_msm_ctx** out, int curve);
 
 /* Bases in HOST memory (arkworks Affine images, `stride` bytes apart).  Copies; caller keeps ownership. */
