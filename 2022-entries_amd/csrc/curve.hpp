@@ -69,6 +69,7 @@ struct FpEl {
 #ifndef MSM_SW_ENTRY_Q
 #define MSM_SW_ENTRY_Q 2
 #endif
+  static constexpr bool ITER_BARRIER = false;
   static constexpr int ENTRY_Q = MSM_SW_ENTRY_Q;   // k_accumulate_glds entry queue: half a sector per refill (155 + 8 VGPRs <= 168)
   static MSM_HD void from_abi(T& r, const uint32_t* w, const Md& md) { fe_from_abi<F>(r, w, md); }
   static MSM_HD void to_abi(uint32_t* w, const T& a, const Md& md) { fe_to_abi<F>(w, a, md); }
@@ -191,6 +192,13 @@ struct Fp2El {
 #ifndef MSM_G2_ENTRY_Q
 #define MSM_G2_ENTRY_Q 0
 #endif
+#ifndef MSM_G2_ITER_BARRIER
+#define MSM_G2_ITER_BARRIER 0
+#endif
+  // k_accumulate_glds: the four waves of a block meet at a barrier every iteration.  The G2 addition is ~118 KB of straight-line
+  // code against a 64-KB instruction cache shared by two CUs, and one wave per SIMD hides no fetch latency: waves that run the
+  // same code at the same time share the fetches
+  static constexpr bool ITER_BARRIER = MSM_G2_ITER_BARRIER != 0;
   static constexpr int ENTRY_Q = MSM_G2_ENTRY_Q;   // no registers to spare (256 VGPRs + AGPRs)
   static MSM_HD void from_abi(T& r, const uint32_t* w, const Md& md) {
     fe_from_abi<F>(r.c0, w, md);

@@ -56,6 +56,7 @@ struct SwLaw {
   static constexpr bool PREFETCH_BASE = E::PREFETCH_BASE;
   static constexpr int GATHER_SECTORS = sizeof(AffineDevT<T>) / 64;   // 64-B sectors of a record that hold data
   static constexpr int ENTRY_Q = E::ENTRY_Q;   // k_accumulate_glds: 16-byte registers of the entry queue (2 entries each); 0 = none
+  static constexpr bool ITER_BARRIER = E::ITER_BARRIER;
   static MSM_HD Base from_dev(const BaseDev& d) { return d.p; }
   static MSM_HD void set_identity(XyzzT<T>& r) { xyzz_set_inf<E>(r); }
   static MSM_HD void begin_run(XyzzT<T>&) {}   // XYZZ: the `fresh` flag makes the first madd a copy
@@ -95,6 +96,7 @@ struct TeLaw {
   static constexpr int ACC_WAVES = TE_ACC_WAVES;
   static constexpr bool PREFETCH_BASE = TE_PREFETCH;
   static constexpr int GATHER_SECTORS = 3;      // (the record may be padded to a 256-byte stride: TE_REC_PAD256, te.hpp)
+  static constexpr bool ITER_BARRIER = false;
   static constexpr int ENTRY_Q = TE_ENTRY_Q;   // a whole 64-B sector of entries per refill: 140 + 16 VGPRs, still three waves per SIMD
   static MSM_HD Base from_dev(const BaseDev& d) { return d.get(); }
   static MSM_HD void set_identity(Xyzz& r) { te_set_identity<F>(r); }

@@ -279,8 +279,17 @@ __global__ void __launch_bounds__(256, G::ACC_WAVES) k_accumulate_glds(const uin
 #if MSM_ACC_PRIO == 3
   if (wave & 1) __builtin_amdgcn_s_sleep(127);
 #endif
-  for (uint32_t k = 0; k < K; k++) {
-    if (__builtin_amdgcn_ballot_w64(alive) == 0) break;   // wave-uniform: every lane of the wave has run out
+  uint32_t trips = K;
+  if constexpr (G::ITER_BARRIER) {
+    // block-uniform trip count: the block's first lane has the most entries (a lane's share is min(K, n_entries - beg))
+    const uint64_t b0 = (uint64_t)blockIdx.x * 256 * K;
+    trips = b0 < n_entries ? (uint32_t)((n_entries - b0 < K) ? n_entries - b0 : K) : 0;
+  }
+  for (uint32_t k = 0; k < trips; k++) {
+    if constexpr (G::ITER_BARRIER)
+      __builtin_amdgcn_s_barrier();   // the block's waves fetch the same instructions at the same time
+    else if (__builtin_amdgcn_ballot_w64(alive) == 0)
+      break;   // wave-uniform: every lane of the wave has run out
     Base p;
 #if MSM_ACC_PRIO == 2
     __builtin_amdgcn_s_setprio(2);

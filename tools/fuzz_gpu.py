@@ -73,6 +73,10 @@ for case in range(cases):
         ctx.set_option("max_chunk", rng.choice([211, 4096]))
     if rng.random() < 0.15:
         ctx.set_option("mem_limit", rng.choice([1 << 20, 16 << 20])); opts["mem_limit"] = 1
+    if rng.random() < 0.3:
+        ctx.set_option("carry", 0); opts["carry"] = 0          # chunks reduce their own buckets (the default carries one bucket array)
+    if special == "" and rng.random() < 0.3:
+        ctx.set_option("assume_subgroup", 1); opts["fold"] = 1  # the generator's points are multiples of G: scalars above r/2 fold
     got = ctx.run(torch.from_numpy(sc).cuda() if rng.random() < 0.5 else sc)[0]
     ctx.close()
     out = ctypes.create_string_buffer(ea.projective_bytes(name))
