@@ -967,7 +967,9 @@ void run_device_t(mi355_msm_ctx* ctx, uint8_t* out, const uint32_t* d_scalars, s
       fit();
       if (off == 0 && !carried && cn < n && ctx->opt_carry) {
         carried = true;
-        carry.c = ctx->plan(n, tables_now).c;   // the window size of the whole batch
+        // the window size of the whole batch -- of at most 2^26 pairs of it: beyond that the model's choice (c = 22) pays a third
+        // grouping pass and a 25-M-bucket merge per chunk (2^28 on one context: 447 ms against 439 at c = 20, tools/big_carry_probe.py)
+        carry.c = ctx->plan(std::min(n, (size_t)1 << 26), tables_now).c;
         carry.index = 0;
         fit();                                  // ... under which a chunk needs other buffers
       }
