@@ -1406,7 +1406,8 @@ RustError mi355_msm_query(mi355_msm_ctx* ctx, const char* key, uint64_t* value) 
         sum += v;
         all &= (v != 0);
       }
-      *value = (k == "twisted_edwards") ? all : ((k == "table_levels" || k == "table_window_bits") ? sum / ctx->shards.size() : sum);
+      *value = (k == "twisted_edwards" || k == "assume_subgroup" || k == "carry") ? all
+                                                                                  : ((k == "table_levels" || k == "table_window_bits") ? sum / ctx->shards.size() : sum);
       return;
     }
     if (k == "twisted_edwards")
@@ -1415,6 +1416,10 @@ RustError mi355_msm_query(mi355_msm_ctx* ctx, const char* key, uint64_t* value) 
       *value = ctx->te_fallbacks;
     else if (k == "twisted_edwards_demotions")
       *value = ctx->te_demotions;
+    else if (k == "assume_subgroup")
+      *value = ctx->opt_assume_subgroup ? 1 : 0;
+    else if (k == "carry")
+      *value = ctx->opt_carry ? 1 : 0;
     else if (k == "oom_backoffs")
       *value = ctx->oom_backoffs;
     else if (k == "chunk_cap")

@@ -212,7 +212,8 @@ class MultiScalarMultContext:
 
     @classmethod
     def from_env(cls, curve="bls12_377_g1") -> "MultiScalarMultContext":
-        """What the harness shims do: honour MI355_MSM_DEVICES ("0,1,2,3", "0-7", "all"; unset = the current device)."""
+        """What the harness shims do: honour MI355_MSM_DEVICES ("0,1,2,3", "0-7", "all"; unset = the current device) and
+        MI355_MSM_ASSUME_SUBGROUP (0 | 1: the context option of that name)."""
         self = cls.__new__(cls)
         self.curve = _curve_id(curve)
         self._lib = load_library()
@@ -261,7 +262,7 @@ class MultiScalarMultContext:
 
     def query(self, key: str) -> int:
         """Context state: "twisted_edwards", "twisted_edwards_fallbacks", "twisted_edwards_demotions", "oom_backoffs", "chunk_cap",
-        "device", "shards", "rccl_exchanges", "bases", "table_levels", "table_window_bits", "base_bytes"."""
+        "device", "shards", "rccl_exchanges", "bases", "table_levels", "table_window_bits", "base_bytes", "assume_subgroup", "carry"."""
         v = ctypes.c_uint64(0)
         _check(self._lib.mi355_msm_query(self.context, key.encode(), ctypes.byref(v)))
         return int(v.value)

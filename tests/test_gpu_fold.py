@@ -96,3 +96,23 @@ def test_default_stays_exact_outside_the_subgroup(ea, oracle):
     ctx.set_option("assume_subgroup", 1)
     assert ea.multi_scalar_mult(ctx, bases, scalars)[0] != exp   # the documented difference
     ctx.close()
+
+
+def test_environment_switch_for_harness_contexts(ea, oracle, monkeypatch):
+    """mi355_msm_create_env (what every harness shim calls): MI355_MSM_ASSUME_SUBGROUP sets the option; unset leaves it off."""
+    curve = m.BLS12_377_G1
+    n = 700
+    bases = ea.generate_points(n, distinct=33, seed=1, curve=curve.name)
+    ks = _scalars_with_edges(curve, n, 2)
+    sc = np.frombuffer(m.encode_scalars([k % curve.r for k in ks]), dtype=np.uint8).reshape(n, 32)
+    exp = oracle_msm_np(oracle, 0, bases, np.ascontiguousarray(sc), n)
+    for env, want in ((None, 0), ("1", 1), ("0", 0)):
+        if env is None:
+            monkeypatch.delenv("MI355_MSM_ASSUME_SUBGROUP", raising=False)
+        else:
+            monkeypatch.setenv("MI355_MSM_ASSUME_SUBGROUP", env)
+        ctx = ea.MultiScalarMultContext.from_env(curve.name)
+        assert ctx.query("assume_subgroup") == want and ctx.query("carry") == 1
+        ctx.set_bases(bases)
+        assert ctx.run(np.ascontiguousarray(sc))[0] == exp
+        ctx.close()
