@@ -593,11 +593,8 @@ __global__ void __launch_bounds__(256) k_collect_sums(const uint4* __restrict__ 
   }
 }
 
-// One chunk of one batch: device scalars [0, n) against bases [base0, base0 + n).  Leaves the folded chunk sum in `out`.
-// TE = true runs the twisted-Edwards kernels (BLS12-377 G1 contexts whose bases all have an image) and returns false when
-// an addition reported a vanishing denominator: the caller then repeats the chunk with TE = false.
 // A batch that runs as several chunks carries ONE bucket array through them (k_bucket_merge): every chunk groups and accumulates
-// with the window size of the whole batch, chunk 0's buckets become the batch's, the later ones are added to them, and only the
+// with the window size of the whole batch (of at most 2^26 pairs of it), chunk 0's buckets become the batch's, the later ones are added to them, and only the
 // last chunk reduces, synchronises and folds.  The chunks before it return the identity and leave their kernels in flight.
 struct BucketCarry {
   uint32_t c;        // window bits of the batch
@@ -615,6 +612,9 @@ hipEvent_t* carry_events(mi355_msm_ctx* ctx, uint32_t index) {
   return ctx->carry_ev.data() + 7 * (size_t)index;
 }
 
+// One chunk of one batch: device scalars [0, n) against bases [base0, base0 + n).  Leaves the folded chunk sum in `out`.
+// TE = true runs the twisted-Edwards kernels (BLS12-377 G1 contexts whose bases all have an image) and returns false when
+// an addition reported a vanishing denominator: the caller then repeats the chunk -- or, when `carry` is set, the whole batch -- with TE = false.
 template <class C, bool TE>
 bool run_chunk_impl(mi355_msm_ctx* ctx, const uint32_t* d_scalars, size_t base0, size_t n, hipStream_t st,
                     typename HostTail<typename C::E>::Pt& out, const std::function<void()>* while_gpu_busy, const BucketCarry* carry = nullptr) {
@@ -822,7 +822,7 @@ bool run_chunk_impl(mi355_msm_ctx* ctx, const uint32_t* d_scalars, size_t base0,
   ctx->last_ms[MI355_T_HOST_FOLD] += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_fold).count();
 
   // stage times: of this chunk, or of every chunk of the carried batch (their events have all completed by now)
-  for (uint32_t k = carry ? 0 : 0, nk = carry ? carry->index + 1 : 1; k < nk; k++) {
+  for (uint32_t k = 0, nk = carry ? carry->index + 1 : 1; k < nk; k++) {
     hipEvent_t* const e = carry ? carry_events(ctx, k) : ctx->ev;
     float ms = 0;
     for (int s = 0; s < 5; s++) {
