@@ -13,6 +13,7 @@
 #include <stdint.h>
 #include <string.h>
 
+#include <algorithm>
 #include <atomic>
 #include <memory>
 #include <mutex>
@@ -184,6 +185,57 @@ void run_on_shards(size_t G, Fn&& fn, Describe&& describe) {
   }
   for (size_t g = 0; g < G; g++)
     if (codes[g]) throw PipelineError(codes[g], describe(g) + ": " + errors[g]);
+}
+
+
+// ---- how the operands of a call are cut into pieces (pure arithmetic; tested on the CPU by tests/tsan_pipeline.cpp) -----------------
+
+// The first batch of a host-scalar run -- whose copy nothing can hide -- is handed over in pieces, each computed while the next one
+// crosses PCIe (CMB MSM.cu:419-434 splits its first copy 1/4 + 3/4; P1A matter-labs/src/lib.rs:171-182 grows its chunks).
+// PCIe delivers 2^26 scalars in ~37 ms and the device works through them in ~110 ms, so a piece can be three times its
+// predecessor: n/div, then x 3 each, the last piece taking what is left.  With carried buckets a piece costs one bucket merge
+// (~1.5 ms at 2^26), so three pieces pay: n/13, 3n/13, 9n/13 -- the device waits for 2.8 ms of copy instead of 9.4.  Without
+// (carry = 0) a piece costs a bucket reduction, a synchronisation and a host fold: 1/4 + 3/4 as before.
+// Returns the piece boundaries (front() = 0, back() = n); two entries = no split.
+inline std::vector<size_t> first_batch_pieces(size_t n, size_t max_chunk, size_t div) {
+  std::vector<size_t> pb{0};
+  if (n >= ((size_t)1 << 23) && div >= 2) {
+    size_t piece = std::min(n / div, max_chunk);
+    while (pb.size() < 7 && piece && pb.back() + piece + piece / 2 < n) {
+      pb.push_back(pb.back() + piece);
+      piece = std::min(piece * 3, max_chunk);
+    }
+  }
+  pb.push_back(n);
+  return pb;
+}
+
+// Slice bounds: short first slices so that the first kernels start early (the growing chunks of P1A matter-labs/src/lib.rs:171-182).
+// ramp = 1: slice/8, slice/2, then full slices -- the compute side waits for 1/8 slice instead of 1/2 before its first kernel;
+// ramp = 0: slice/2, then full slices (the first version; kept for the A/B of profiles/r03_stateless_probe.txt).
+// ramp_down (carried buckets only: a further slice then costs one merge, not a bucket reduction): the call ends with slices of
+// slice/2, slice/4, slice/8 -- what is left to compute when the last byte has crossed PCIe is an eighth of a slice and the one
+// bucket reduction, instead of a whole slice.
+inline std::vector<size_t> stateless_slices(size_t n, size_t slice, int ramp, bool ramp_down = false) {
+  std::vector<size_t> lo{0};
+  if (n == 0) return {0, 0};
+  std::vector<size_t> down;
+  if (ramp_down && slice >= 64 && n >= 4 * slice) down = {slice / 2, slice / 4, slice / 8};
+  size_t tail = 0;
+  for (size_t d : down) tail += d;
+  const size_t body = n - tail;   // what the ramp-up and the full slices cover
+  if (body > slice + slice / 2) {
+    if (ramp && slice >= 64) lo.push_back(slice / 8);
+    lo.push_back(lo.back() + slice / 2);
+  }
+  while (lo.back() + slice < body) {
+    // do not leave a sliver for the last slice: it would pay a whole bucket reduction (or merge) for a few pairs
+    if (body - (lo.back() + slice) < slice / 4) break;
+    lo.push_back(lo.back() + slice);
+  }
+  lo.push_back(body);
+  for (size_t d : down) lo.push_back(lo.back() + d);
+  return lo;
 }
 
 }  // namespace msm_host

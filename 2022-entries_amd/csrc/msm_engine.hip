@@ -891,26 +891,6 @@ struct HostBatches {
   void copy(size_t b) const { copy_pairs(b, 0, batch_bytes / 32, ready[b & 1]); }
 };
 
-// The first batch of a host-scalar run -- whose copy nothing can hide -- is handed over in pieces, each computed while the next one
-// crosses PCIe (CMB MSM.cu:419-434 splits its first copy 1/4 + 3/4; P1A matter-labs/src/lib.rs:171-182 grows its chunks).
-// PCIe delivers 2^26 scalars in ~37 ms and the device works through them in ~110 ms, so a piece can be three times its
-// predecessor: n/div, then x 3 each, the last piece taking what is left.  With carried buckets a piece costs one bucket merge
-// (~1.5 ms at 2^26), so three pieces pay: n/13, 3n/13, 9n/13 -- the device waits for 2.8 ms of copy instead of 9.4.  Without
-// (carry = 0) a piece costs a bucket reduction, a synchronisation and a host fold: 1/4 + 3/4 as before.
-// Returns the piece boundaries (front() = 0, back() = n); two entries = no split.
-inline std::vector<size_t> first_batch_pieces(size_t n, size_t max_chunk, size_t div) {
-  std::vector<size_t> pb{0};
-  if (n >= ((size_t)1 << 23) && div >= 2) {
-    size_t piece = std::min(n / div, max_chunk);
-    while (pb.size() < 7 && piece && pb.back() + piece + piece / 2 < n) {
-      pb.push_back(pb.back() + piece);
-      piece = std::min(piece * 3, max_chunk);
-    }
-  }
-  pb.push_back(n);
-  return pb;
-}
-
 // `dev_batch_pairs`: distance (in scalars) between two batches in the device buffer (n, or the total of a sharded run when a
 // shard reads its slice in place).
 template <class C>
@@ -925,7 +905,7 @@ void run_device_t(mi355_msm_ctx* ctx, uint8_t* out, const uint32_t* d_scalars, s
   ctx->chunk_cap = 0;
   const size_t out_bytes = 3 * 4 * E::WORDS;
   const size_t div = ctx->opt_first_piece_div ? (size_t)ctx->opt_first_piece_div : (ctx->opt_carry ? 13 : 4);
-  const std::vector<size_t> pb = (hb && batches) ? first_batch_pieces(n, max_chunk, div) : std::vector<size_t>{0, n};
+  const std::vector<size_t> pb = (hb && batches) ? msm_host::first_batch_pieces(n, max_chunk, div) : std::vector<size_t>{0, n};
   const size_t P = pb.size() - 1;   // pieces of batch 0
   size_t issued = 0;                // ... whose copy has been issued
   std::vector<char> awaited(P, 0);

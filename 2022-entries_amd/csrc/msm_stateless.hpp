@@ -161,34 +161,6 @@ struct Uploader : msm_host::UploaderT<HipPipelineApi> {
   }
 };
 
-// Slice bounds: short first slices so that the first kernels start early (the growing chunks of P1A matter-labs/src/lib.rs:171-182).
-// ramp = 1: slice/8, slice/2, then full slices -- the compute side waits for 1/8 slice instead of 1/2 before its first kernel;
-// ramp = 0: slice/2, then full slices (the first version; kept for the A/B of profiles/r03_stateless_probe.txt).
-// ramp_down (carried buckets only: a further slice then costs one merge, not a bucket reduction): the call ends with slices of
-// slice/2, slice/4, slice/8 -- what is left to compute when the last byte has crossed PCIe is an eighth of a slice and the one
-// bucket reduction, instead of a whole slice.
-std::vector<size_t> stateless_slices(size_t n, size_t slice, int ramp, bool ramp_down = false) {
-  std::vector<size_t> lo{0};
-  if (n == 0) return {0, 0};
-  std::vector<size_t> down;
-  if (ramp_down && slice >= 64 && n >= 4 * slice) down = {slice / 2, slice / 4, slice / 8};
-  size_t tail = 0;
-  for (size_t d : down) tail += d;
-  const size_t body = n - tail;   // what the ramp-up and the full slices cover
-  if (body > slice + slice / 2) {
-    if (ramp && slice >= 64) lo.push_back(slice / 8);
-    lo.push_back(lo.back() + slice / 2);
-  }
-  while (lo.back() + slice < body) {
-    // do not leave a sliver for the last slice: it would pay a whole bucket reduction (or merge) for a few pairs
-    if (body - (lo.back() + slice) < slice / 4) break;
-    lo.push_back(lo.back() + slice);
-  }
-  lo.push_back(body);
-  for (size_t d : down) lo.push_back(lo.back() + d);
-  return lo;
-}
-
 template <class C>
 void stateless_t(mi355_msm_ctx* ctx, uint8_t* out, const uint8_t* affine, size_t n, const uint8_t* scalars, size_t stride) {
   using E = typename C::E;
@@ -213,7 +185,7 @@ void stateless_t(mi355_msm_ctx* ctx, uint8_t* out, const uint8_t* affine, size_t
     const long auto_log = std::min<long>(23, std::max<long>(20, (long)ilog2_floor(std::max<size_t>(n, 4) / 4)));
     const size_t slice = (size_t)1 << env_long("MI355_MSM_STATELESS_SLICE_LOG", auto_log, 10, 26);
     const bool want_carry = ctx->opt_carry && env_long("MI355_MSM_STATELESS_CARRY", 0, 0, 1);
-    const std::vector<size_t> lo = stateless_slices(n, slice, (int)env_long("MI355_MSM_STATELESS_RAMP", 1, 0, 1),
+    const std::vector<size_t> lo = msm_host::stateless_slices(n, slice, (int)env_long("MI355_MSM_STATELESS_RAMP", 1, 0, 1),
                                                     env_long("MI355_MSM_STATELESS_RAMP_DOWN", 0, 0, 1) != 0);
     const uint32_t S = (uint32_t)lo.size() - 1;
     size_t max_cnt = 0;

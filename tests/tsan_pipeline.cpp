@@ -196,7 +196,57 @@ static size_t run_pipeline(uint32_t slices, size_t pairs, size_t stride, size_t 
   return result ? result : mismatches.load();
 }
 
+// The cuts of a call's operands (host_pipeline.hpp): every pair belongs to exactly one piece, pieces grow as documented.
+static bool check_cuts() {
+  using msm_host::first_batch_pieces;
+  using msm_host::stateless_slices;
+  auto partition_of = [](const std::vector<size_t>& b, size_t n) {
+    if (b.size() < 2 || b.front() != 0 || b.back() != n) return false;
+    for (size_t i = 1; i < b.size(); i++)
+      if (b[i] < b[i - 1] || (b[i] == b[i - 1] && n != 0)) return false;
+    return true;
+  };
+  const size_t N = (size_t)1 << 26, MC = (size_t)1 << 26;
+  // first host-scalar batch: n/div, then x 3, the last piece takes the rest; no split below 2^23 pairs
+  if (first_batch_pieces(N, MC, 13) != std::vector<size_t>{0, N / 13, N / 13 + 3 * (N / 13), N}) return false;
+  if (first_batch_pieces(N, MC, 4) != std::vector<size_t>{0, N / 4, N}) return false;
+  if (first_batch_pieces(N, MC, 40).size() != 5) return false;
+  if (first_batch_pieces(((size_t)1 << 23) - 1, MC, 13) != std::vector<size_t>{0, ((size_t)1 << 23) - 1}) return false;
+  if (first_batch_pieces(0, MC, 13) != std::vector<size_t>{0, 0}) return false;
+  for (size_t n : {(size_t)1 << 23, ((size_t)1 << 23) + 7, (size_t)3 << 24, N + 12345, (size_t)1 << 28})
+    for (size_t div : {2, 4, 8, 13, 16, 40, 64})
+      for (size_t mc : {(size_t)1 << 20, (size_t)1 << 26}) {
+        const std::vector<size_t> b = first_batch_pieces(n, mc, div);
+        if (!partition_of(b, n) || b.size() > 8) return false;
+        for (size_t i = 1; i + 1 < b.size(); i++)
+          if (b[i] - b[i - 1] > mc) return false;   // every piece but the last fits a chunk
+      }
+  // stateless slices: a 1/8 + 1/2 ramp, full slices, optionally a 1/2 + 1/4 + 1/8 ramp-down; no slivers
+  const size_t S = (size_t)1 << 23;
+  if (stateless_slices(0, S, 1) != std::vector<size_t>{0, 0}) return false;
+  if (stateless_slices(S, S, 1) != std::vector<size_t>{0, S}) return false;
+  const std::vector<size_t> a = stateless_slices(N, S, 1);
+  if (!partition_of(a, N) || a[1] != S / 8 || a[2] != S / 8 + S / 2 || a.size() != 11) return false;
+  const std::vector<size_t> d = stateless_slices(N, S, 1, true);
+  if (!partition_of(d, N) || d[d.size() - 1] - d[d.size() - 2] != S / 8 || d[d.size() - 2] - d[d.size() - 3] != S / 4) return false;
+  for (size_t n : {(size_t)1, (size_t)1000, S - 1, S + 1, 3 * S / 2 + 1, 5 * S + 17, N + 999})
+    for (size_t slice : {(size_t)64, (size_t)1 << 20, S})
+      for (int ramp : {0, 1})
+        for (bool down : {false, true}) {
+          const std::vector<size_t> b = stateless_slices(n, slice, ramp, down);
+          if (!partition_of(b, n)) return false;
+          for (size_t i = 1; i < b.size(); i++)
+            if (b[i] - b[i - 1] > slice + slice / 2 + slice / 4) return false;   // the last full slice may absorb a remainder below slice/4 ... of the body
+        }
+  return true;
+}
+
 int main() {
+  if (!check_cuts()) {
+    fprintf(stderr, "piece / slice boundaries are wrong\n");
+    return 1;
+  }
+  printf("piece and slice boundaries: partitions of the input, documented shapes\n");
   // many small pieces: the ring of 12 slots wraps dozens of times, the three raw buffers a few times
   struct Case {
     uint32_t slices;
