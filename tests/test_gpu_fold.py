@@ -116,3 +116,24 @@ def test_environment_switch_for_harness_contexts(ea, oracle, monkeypatch):
         ctx.set_bases(bases)
         assert ctx.run(np.ascontiguousarray(sc))[0] == exp
         ctx.close()
+
+
+@pytest.mark.parametrize("cid,curve", CURVES)
+def test_every_scalar_folded_and_sharded_contexts(ea, oracle, cid, curve):
+    """All scalars in (r/2, r) -- every one of them runs as (r - k)(-P) -- and none (all below r/2); tiny inputs; a sharded context
+    (the option is forwarded to every shard)."""
+    rng = np.random.default_rng(17 + cid)
+    r = curve.r
+    for n in (1, 2, 64, 3001):
+        bases = ea.generate_points(n, distinct=min(n, 41), seed=n, curve=curve.name)
+        hi = [r // 2 + 1 + int.from_bytes(rng.bytes(32), "little") % (r // 2 - 1) for _ in range(n)]
+        lo = [int.from_bytes(rng.bytes(32), "little") % (r // 2) for _ in range(n)]
+        for ks in (hi, lo):
+            sc = np.frombuffer(m.encode_scalars(ks), dtype=np.uint8).reshape(n, 32)
+            exp = oracle_msm_np(oracle, cid, bases, np.ascontiguousarray(sc), n)
+            for devices in (None, [0, 0, 0]):
+                ctx = ea.multi_scalar_mult_init(bases, curve.name, devices=devices) if devices else ea.multi_scalar_mult_init(bases, curve.name)
+                ctx.set_option("assume_subgroup", 1)
+                assert ctx.query("assume_subgroup") == 1
+                assert ctx.run(np.ascontiguousarray(sc))[0] == exp, (n, devices)
+                ctx.close()
