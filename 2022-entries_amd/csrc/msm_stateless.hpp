@@ -193,7 +193,8 @@ void stateless_t(mi355_msm_ctx* ctx, uint8_t* out, const uint8_t* affine, size_t
 
     // the slices share one bucket array (BucketCarry, msm_engine.hip): every slice groups and accumulates with the window size of
     // the whole call, only the last one reduces; 0 = every slice reduces its own buckets with its own window size
-    const uint32_t carry_c = (S > 1 && want_carry) ? ctx->plan(std::min(n, (size_t)1 << 26), false).c : 0;
+    const long forced_c = env_long("MI355_MSM_STATELESS_CARRY_C", 0, 0, 23);   // A/B only: the carried slices' window size
+    const uint32_t carry_c = (S > 1 && want_carry) ? (forced_c ? (uint32_t)forced_c : ctx->plan(std::min(n, (size_t)1 << 26), false).c) : 0;
     BucketCarry carry{carry_c, 0, true, false};
     const bool trace = env_long("MI355_MSM_STATELESS_TRACE", 0, 0, 1) != 0;   // per-slice timeline on stderr
     std::vector<double> tr_ready(S), tr_done(S);
