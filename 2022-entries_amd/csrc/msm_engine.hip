@@ -248,11 +248,13 @@ struct mi355_msm_ctx {
     p.half = 1u << (p.c - 1);
     p.keybits = ilog2_floor(p.bucket_windows * p.half) + 1;   // bits of a bucket key (reported by mi355_msm_plan)
     p.entries = (uint64_t)p.windows * n;
-    // entries per accumulate lane: 2^20 lanes at full size; below that fewer, longer lanes win until the chip would go idle
+    // entries per accumulate lane: 2^20 lanes up to 2^25 pairs (then 512 entries each); below that fewer, longer lanes win until the chip would go idle
     // (tools/small_k_sweep.py: 24 instead of 8 at 2^17..2^19 pairs: -4..-11 % wall; 36..64 instead of 18..36 at 2^20..2^21: -3 %)
     // (and 4 below 2^18 entries -- a few thousand pairs -- where even 8 additions in a row are a visible share: -4 %)
     const uint64_t k_auto = std::max<uint64_t>({p.entries >= (3u << 20) ? 24u : (p.entries < (1u << 18) ? 4u : 8u), p.entries >> 20, std::min<uint64_t>(64, p.entries >> 19)});
-    uint32_t K = opt_lane_entries ? (uint32_t)opt_lane_entries : (uint32_t)std::min<uint64_t>(256, k_auto);
+    // (capped at 512 since round 3, 256 before: the accumulation takes the same time for 128..1024 entries per lane, the fragment
+    //  merge halves with the lane count -- 2^26: 109.0 -> 108.5 ms, 2^25: 57.0 -> 56.8, BLS12-381 flat; profiles/r03_ab_lane_entries.txt)
+    uint32_t K = opt_lane_entries ? (uint32_t)opt_lane_entries : (uint32_t)std::min<uint64_t>(512, k_auto);
     p.K = K >= 8 ? (K + 7) & ~7u : (K + 3) & ~3u;   // a lane's entries start on a 64-byte boundary (k_accumulate_glds refills its entry queue by whole sectors)
     p.nlanes = ceil_div(p.entries, p.K);
     p.segK = opt_seg_entries >= 4 ? (uint32_t)opt_seg_entries : (p.entries < (2u << 20) ? 4 : 8);   // small inputs: shallower levels (-1..-3 %)
