@@ -1,5 +1,6 @@
 import sys, time
-sys.path.insert(0, "/root/repo")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, numpy as np
 import entries_amd as ea, bench
 dev = torch.device("cuda", 0)

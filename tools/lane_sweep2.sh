@@ -1,4 +1,6 @@
-cd /root/repo
+#!/bin/bash
+# On the GPU box: entries per accumulate lane on BLS12-381 2^26, BLS12-377 2^25 and 2^26 (profiles/r03_ab_lane_entries.txt).
+cd "$(dirname "$0")/.."
 run() { python bench.py --steps 6 --warmup 2 --cpu-sample-pow 0 --extras 0 --also-precompute 0 "$@" 2>/dev/null | python -c "
 import json,sys
 j=json.loads(sys.stdin.read().strip().splitlines()[-1]); s=j['stage_ms_per_step']
