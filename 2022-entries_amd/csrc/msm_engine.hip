@@ -151,9 +151,11 @@ int choose_window_bits(size_t n, int scalar_bits, bool shared_buckets, bool fold
   for (int c = 2; c <= (shared_buckets ? 24 : 23); c++) {
     // folded scalars (assume_subgroup) are < r/2: one bit less, and when c divides that the window above only takes the carry
     // of the scalars whose top digit exceeds 2^(c-1): (r/2 - 2^(bits-1)) / (r/2) = 14.5 % (BLS12-377), 44.8 % (BLS12-381)
-    const int bits = fold ? scalar_bits - 1 : scalar_bits;
+    // (only from 2^25 pairs on: that is where it was measured to pay -- BLS12-377 G1 2^26, c = 21: 110.2 -> 108.3 ms; below, the model's
+    //  margin is inside its error: G2 2^24 chose c = 18 and lost 4 %, profiles/r03_ab_fold.txt)
+    const int bits = (fold && n >= ((size_t)1 << 25)) ? scalar_bits - 1 : scalar_bits;
     const int full = bits / c, rem = bits - full * c;
-    const double eff = full + (rem >= 2 ? 1.0 : (fold && rem == 0 ? (scalar_bits == 253 ? 0.145 : 0.448) : 0.55));
+    const double eff = full + (rem >= 2 ? 1.0 : (bits != scalar_bits && rem == 0 ? (scalar_bits == 253 ? 0.145 : 0.448) : 0.55));
     const double alloc = shared_buckets ? 1.0 : (double)((257 + c - 1) / c);
     const double cost = eff * (double)n * 10.0 + alloc * (double)(1ull << (c - 1)) * 50.0;
     if (cost < best_cost) { best_cost = cost; best = c; }
