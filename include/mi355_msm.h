@@ -128,7 +128,7 @@ RustError mi355_msm_run_device(mi355_msm_ctx* ctx, void* out_projective, const v
  * "assume_subgroup" = 1 (default 0): the caller guarantees that every base lies in the order-r subgroup (r P = O), as the ZPrize
  * generator's do.  A scalar k in (r/2, r) then runs as (r - k)(-P): the winners' top-bit trick (CMB ProcessSignedDigits.cu:10-20,
  * 123-128), one significant bit less, so BLS12-377 scalars tile 12 windows of 21 bits and the auto window size moves from 20 to 21
- * at 2^26 pairs (-5 % additions).  Off by default because arkworks' msm is exact for ANY curve point and this is not.
+ * at 2^26 pairs (-5 % additions; below 2^25 pairs the window choice is left alone).  Off by default because arkworks' msm is exact for ANY curve point and this is not.
  * "carry" (default 1): a batch that runs as several chunks (max_chunk, the memory budget, the pieces of a host-scalar batch) carries
  * ONE bucket array through them -- every chunk uses the window size of the whole batch and only the last one reduces; 0 = every
  * chunk reduces its own buckets and the partial sums are added on the host.  "first_piece_div" (default 13; 4 with carry = 0): the
