@@ -160,3 +160,18 @@ def test_host_scalar_batches_split_their_first_piece(ea, cid):
         assert ctx.run(sc) == ref, (div, carry)
         assert ctx.last_timings()["launches"] == pieces + 1, (div, carry)
     ctx.close()
+
+
+def test_golden_vectors_in_carried_chunks(ea, golden):
+    """Every golden case (incl. the FPGA harness's edge fixtures: P, -P, the 2-torsion point T twice, special points at chunk
+    boundaries -- P1B hardcaml msm_unit_tests.rs:21-242) as chunks of 5 and of 16 pairs over carried buckets, and with per-chunk
+    reductions: the special points meet at OUR chunk boundaries and in the bucket merge, on all three curves."""
+    for case in golden:
+        bases, scalars = bytes.fromhex(case["bases"]), bytes.fromhex(case["scalars"])
+        ctx = ea.multi_scalar_mult_init(bases, case["curve"])
+        for chunk in (5, 16):
+            ctx.set_option("max_chunk", chunk)
+            for carry in (1, 0):
+                ctx.set_option("carry", carry)
+                assert ea.multi_scalar_mult(ctx, bases, scalars)[0].hex() == case["expected"], (case["curve"], case["name"], chunk, carry)
+        ctx.close()
