@@ -84,6 +84,10 @@ inline PartPlan part_plan(uint32_t n, uint32_t c, uint32_t windows, bool shared,
   // ... but the bits it leaves must fit the low half of an entry's key word (the bin rides in the high half while an entry is
   // staged in LDS): a small input with a large forced window would otherwise leave up to 23
   if (bits - p.hb > 15) p.hb = bits - 15;
+  // ... and a level-1 bit is cheaper than a whole extra generic pass (every pass moves all entries once more): a chunk of a carried
+  // batch is small but runs at the window size of the batch -- 5 M pairs at c = 20 would leave 12 bits, two passes
+  if (bits - p.hb > (uint32_t)PART_MAX_RB && bits - (uint32_t)PART_MAX_RB <= (uint32_t)PART_MAX_HB && bits - p.hb <= 2 * (uint32_t)PART_MAX_RB)
+    p.hb = bits - (uint32_t)PART_MAX_RB;
   p.lb = bits - p.hb;
   p.b1 = 1u << p.hb;
   p.nbins = windows * p.b1;
