@@ -31,13 +31,13 @@ hipError_t LaunchTe::segreduce(const XyzzDev* in_slots, const uint32_t* in_keys,
   return hipGetLastError();
 }
 
-hipError_t LaunchTe::bucket_reduce(bool first, const XyzzDev* in_a, const XyzzDev* in_x, uint32_t n_per_win, uint32_t logL, uint32_t chunks,
-                                   uint32_t windows, XyzzDev* out_a, XyzzDev* out_x, uint32_t* flags, hipStream_t st) {
+hipError_t LaunchTe::bucket_reduce(bool first, const XyzzDev* in_a, const XyzzDev* in_x, uint32_t n_per_win, uint32_t L, uint32_t chunks,
+                                   uint32_t windows, uint32_t out_stride, XyzzDev* out_a, XyzzDev* out_x, uint32_t* flags, hipStream_t st) {
   dim3 grid(te_blocks((uint64_t)windows * chunks));
   if (first)
-    hipLaunchKernelGGL((k_bucket_reduce<G, true>), grid, dim3(256), 0, st, in_a, in_x, n_per_win, logL, chunks, windows, out_a, out_x, flags);
+    hipLaunchKernelGGL((k_bucket_reduce<G, true>), grid, dim3(256), 0, st, in_a, in_x, n_per_win, L, chunks, windows, out_stride, out_a, out_x, flags);
   else
-    hipLaunchKernelGGL((k_bucket_reduce<G, false>), grid, dim3(256), 0, st, in_a, in_x, n_per_win, logL, chunks, windows, out_a, out_x, flags);
+    hipLaunchKernelGGL((k_bucket_reduce<G, false>), grid, dim3(256), 0, st, in_a, in_x, n_per_win, L, chunks, windows, out_stride, out_a, out_x, flags);
   return hipGetLastError();
 }
 

@@ -25,8 +25,8 @@ struct Launch {
   static hipError_t pre_double(const AffineDevT<El>* in, const uint8_t* inf_in, uint32_t n, uint32_t c, XyzzDevT<El>* out, hipStream_t st);
   static hipError_t pre_normalize(const XyzzDevT<El>* in, uint32_t n, uint32_t J, El* prefix, AffineDevT<El>* out, uint8_t* inf_out,
                                   hipStream_t st);
-  static hipError_t bucket_reduce(bool first, const XyzzDevT<El>* in_a, const XyzzDevT<El>* in_x, uint32_t n_per_win, uint32_t logL,
-                                  uint32_t chunks, uint32_t windows, XyzzDevT<El>* out_a, XyzzDevT<El>* out_x, hipStream_t st);
+  static hipError_t bucket_reduce(bool first, const XyzzDevT<El>* in_a, const XyzzDevT<El>* in_x, uint32_t n_per_win, uint32_t L,
+                                  uint32_t chunks, uint32_t windows, uint32_t out_stride, XyzzDevT<El>* out_a, XyzzDevT<El>* out_x, hipStream_t st);
   // small windows: one step of the scan-based reduction (k_reduce_scan_step)
   static hipError_t reduce_scan_step(const XyzzDevT<El>* in, const XyzzDevT<El>* in2, XyzzDevT<El>* out, uint32_t nb, uint32_t windows, uint32_t d, uint32_t mode,
                                      uint32_t quad_limit, hipStream_t st);
@@ -44,8 +44,8 @@ struct LaunchTe {
                                const TeAffineDev* bases, SegOut out, uint32_t nlanes, uint32_t* flags, hipStream_t st);
   static hipError_t segreduce(const XyzzDev* in_slots, const uint32_t* in_keys, uint32_t n_in, uint32_t K, SegOut out, uint32_t nlanes,
                               uint32_t quad_limit, uint32_t* flags, hipStream_t st);
-  static hipError_t bucket_reduce(bool first, const XyzzDev* in_a, const XyzzDev* in_x, uint32_t n_per_win, uint32_t logL, uint32_t chunks,
-                                  uint32_t windows, XyzzDev* out_a, XyzzDev* out_x, uint32_t* flags, hipStream_t st);
+  static hipError_t bucket_reduce(bool first, const XyzzDev* in_a, const XyzzDev* in_x, uint32_t n_per_win, uint32_t L, uint32_t chunks,
+                                  uint32_t windows, uint32_t out_stride, XyzzDev* out_a, XyzzDev* out_x, uint32_t* flags, hipStream_t st);
   static hipError_t reduce_scan_step(const XyzzDev* in, const XyzzDev* in2, XyzzDev* out, uint32_t nb, uint32_t windows, uint32_t d, uint32_t mode,
                                      uint32_t quad_limit, uint32_t* flags, hipStream_t st);
   static hipError_t bucket_merge(XyzzDev* total, const XyzzDev* part, uint32_t n, uint32_t* flags, hipStream_t st);

@@ -47,14 +47,14 @@ hipError_t Launch<E>::segreduce(const XyzzDevT<El>* in_slots, const uint32_t* in
 }
 
 template <class E>
-hipError_t Launch<E>::bucket_reduce(bool first, const XyzzDevT<El>* in_a, const XyzzDevT<El>* in_x, uint32_t n_per_win, uint32_t logL,
-                                    uint32_t chunks, uint32_t windows, XyzzDevT<El>* out_a, XyzzDevT<El>* out_x, hipStream_t st) {
+hipError_t Launch<E>::bucket_reduce(bool first, const XyzzDevT<El>* in_a, const XyzzDevT<El>* in_x, uint32_t n_per_win, uint32_t L,
+                                    uint32_t chunks, uint32_t windows, uint32_t out_stride, XyzzDevT<El>* out_a, XyzzDevT<El>* out_x, hipStream_t st) {
   dim3 grid(launch_blocks((uint64_t)windows * chunks));
   if (first)
-    hipLaunchKernelGGL((k_bucket_reduce<SwLaw<E>, true>), grid, dim3(256), 0, st, in_a, in_x, n_per_win, logL, chunks, windows, out_a, out_x,
+    hipLaunchKernelGGL((k_bucket_reduce<SwLaw<E>, true>), grid, dim3(256), 0, st, in_a, in_x, n_per_win, L, chunks, windows, out_stride, out_a, out_x,
                        (uint32_t*)nullptr);
   else
-    hipLaunchKernelGGL((k_bucket_reduce<SwLaw<E>, false>), grid, dim3(256), 0, st, in_a, in_x, n_per_win, logL, chunks, windows, out_a, out_x,
+    hipLaunchKernelGGL((k_bucket_reduce<SwLaw<E>, false>), grid, dim3(256), 0, st, in_a, in_x, n_per_win, L, chunks, windows, out_stride, out_a, out_x,
                        (uint32_t*)nullptr);
   return hipGetLastError();
 }

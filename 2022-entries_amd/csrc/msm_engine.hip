@@ -171,6 +171,8 @@ struct Plan {
   uint32_t segK;        // fragment-merge fan-in
   uint32_t logL0, logL; // bucket-reduce chunk sizes
   uint32_t T0;          // chunks per window on the first reduce level
+  uint32_t L0;          // buckets per chunk there (2^logL0, or -- before a scan -- whatever fills the chip's SIMDs with one wave each)
+  uint32_t scan_nb;     // elements per window the scan runs on: T0 rounded up to a power of two (the tail of a row stays empty)
   bool reduce_scan;     // finish the bucket reduction by a parallel scan (k_reduce_scan_step) ...
   bool scan_direct;     // ... directly on the buckets (small windows), or after one chunked level
 };
@@ -281,7 +283,27 @@ struct mi355_msm_ctx {
       else if (p.logL0 < need)
         p.logL0 = need;
     }
-    p.T0 = ceil_div(p.half, 1u << p.logL0);
+    p.L0 = 1u << p.logL0;
+    p.T0 = ceil_div(p.half, p.L0);
+    p.scan_nb = p.T0;
+    if (p.reduce_scan && !p.scan_direct && !opt_reduce_log_chunk && !opt_reduce_log_chunk0) {
+      // The first level is one wave per SIMD (an accumulator chain per lane, 53 K lanes): 13 windows x 4096 chunks are 832 waves on
+      // the 1024 SIMDs of an MI355X -- a fifth of the chip idles while every lane walks 128 buckets.  Cut the window into as many
+      // chunks as fill the SIMDs once (4994 chunks of 105 buckets = 1015 waves) and let the scan run on the next power of two.
+      const uint64_t kSimds = 1024;   // 256 CUs x 4 (the plan is also computed without a device: mi355_msm_plan)
+      const uint64_t waves = ((uint64_t)p.bucket_windows * p.T0 + 63) / 64;
+      if (waves < kSimds && p.T0 >= 1024) {
+        const uint32_t t_fit = (uint32_t)(kSimds * 64 / p.bucket_windows);
+        if (t_fit > p.T0 && t_fit < 2 * p.T0) {
+          const uint32_t L = ceil_div(p.half, t_fit);
+          if (L >= 8 && L < p.L0) {
+            p.L0 = L;
+            p.T0 = ceil_div(p.half, L);
+            p.scan_nb = 2 * p.scan_nb;   // T0 < 2 x the old power of two
+          }
+        }
+      }
+    }
     return p;
   }
 };
@@ -323,7 +345,7 @@ uint64_t work_bytes(const Plan& p, uint64_t el, bool carry = false) {
   const PartPlan pp = part_plan((uint32_t)(p.entries / p.windows), p.c, p.windows, p.bucket_windows == 1 && p.windows > 1, 0, 0);
   const PartScratchSizes ps = part_scratch_sizes(pp);
   return p.entries * 16 + ps.matrix + ps.partial + ps.segs_a + ps.segs_b + ps.subjob_first + ps.counts + ps.totals +
-         (uint64_t)p.bucket_windows * p.half * 224 * el * (carry ? 2 : 1) + 2 * (2ull * p.nlanes) * (224 * el + 4) + (p.scan_direct ? (uint64_t)p.bucket_windows * p.half : 4ull * p.bucket_windows * p.T0) * 224 * el;
+         (uint64_t)p.bucket_windows * p.half * 224 * el * (carry ? 2 : 1) + 2 * (2ull * p.nlanes) * (224 * el + 4) + (p.scan_direct ? (uint64_t)p.bucket_windows * p.half : 4ull * p.bucket_windows * p.scan_nb) * 224 * el;
 }
 
 DevBuf* const* work_buffers(mi355_msm_ctx* ctx, size_t& count) {
@@ -351,7 +373,7 @@ WorkBytes chunk_work_bytes(const Plan& p, size_t n, bool use_tables, size_t xyzz
   const PartPlan gp = part_plan((uint32_t)n, p.c, p.windows, use_tables, 0, 0);
   const PartScratchSizes gs = part_scratch_sizes(gp);
   const size_t nbuckets = (size_t)p.bucket_windows * p.half, nslots0 = 2 * (size_t)p.nlanes;
-  const size_t red0 = p.scan_direct ? nbuckets : (size_t)p.bucket_windows * p.T0;   // direct scan: a second bucket-sized array to ping-pong with
+  const size_t red0 = p.scan_direct ? nbuckets : (size_t)p.bucket_windows * p.scan_nb;   // direct scan: a second bucket-sized array to ping-pong with
   w.b[0] = w.b[1] = p.entries * 8 + 64;
   w.b[2] = gs.matrix;
   w.b[3] = gs.partial;
@@ -738,13 +760,18 @@ bool run_chunk_impl(mi355_msm_ctx* ctx, const uint32_t* d_scalars, size_t base0,
     XyzzDev* bufs[2] = {bucket_src, ctx->red_a[0].as<XyzzDev>()};
     const XyzzDev* a_sums = nullptr;
     if (!p.scan_direct) {
+      if (p.scan_nb != p.T0) {
+        // rows of scan_nb elements, T0 of them written: the rest must read as empty
+        HIP_OK(hipMemsetAsync(ctx->red_a[0].p, 0, (size_t)p.bucket_windows * p.scan_nb * sizeof(XyzzDev), st));
+        HIP_OK(hipMemsetAsync(ctx->red_x[0].p, 0, (size_t)p.bucket_windows * p.scan_nb * sizeof(XyzzDev), st));
+      }
       if constexpr (TE)
-        HIP_OK(LaunchTe::bucket_reduce(true, nullptr, bucket_src, p.half, p.logL0, p.T0, p.bucket_windows,
+        HIP_OK(LaunchTe::bucket_reduce(true, nullptr, bucket_src, p.half, p.L0, p.T0, p.bucket_windows, p.scan_nb,
                                        ctx->red_a[0].as<XyzzDev>(), ctx->red_x[0].as<XyzzDev>(), flags, st));
       else
-        HIP_OK(Launch<E>::bucket_reduce(true, nullptr, bucket_src, p.half, p.logL0, p.T0, p.bucket_windows,
+        HIP_OK(Launch<E>::bucket_reduce(true, nullptr, bucket_src, p.half, p.L0, p.T0, p.bucket_windows, p.scan_nb,
                                         ctx->red_a[0].as<XyzzDev>(), ctx->red_x[0].as<XyzzDev>(), st));
-      nb = p.T0;
+      nb = p.scan_nb;
       a_sums = ctx->red_a[0].as<XyzzDev>();
       bufs[0] = ctx->red_x[0].as<XyzzDev>();
       bufs[1] = ctx->red_x[1].as<XyzzDev>();
@@ -770,21 +797,21 @@ bool run_chunk_impl(mi355_msm_ctx* ctx, const uint32_t* d_scalars, size_t base0,
     uint32_t n_per_win = p.half, logL = p.logL0, chunks = p.T0;
     int rb = 0;
     if constexpr (TE)
-      HIP_OK(LaunchTe::bucket_reduce(true, nullptr, bucket_src, n_per_win, logL, chunks, p.bucket_windows,
+      HIP_OK(LaunchTe::bucket_reduce(true, nullptr, bucket_src, n_per_win, 1u << logL, chunks, p.bucket_windows, chunks,
                                      ctx->red_a[0].as<XyzzDev>(), ctx->red_x[0].as<XyzzDev>(), flags, st));
     else
-      HIP_OK(Launch<E>::bucket_reduce(true, nullptr, bucket_src, n_per_win, logL, chunks, p.bucket_windows,
+      HIP_OK(Launch<E>::bucket_reduce(true, nullptr, bucket_src, n_per_win, 1u << logL, chunks, p.bucket_windows, chunks,
                                       ctx->red_a[0].as<XyzzDev>(), ctx->red_x[0].as<XyzzDev>(), st));
     while (chunks > 1) {
       n_per_win = chunks;
       logL = p.logL;
       chunks = ceil_div(n_per_win, 1u << logL);
       if constexpr (TE)
-        HIP_OK(LaunchTe::bucket_reduce(false, ctx->red_a[rb].as<XyzzDev>(), ctx->red_x[rb].as<XyzzDev>(), n_per_win, logL, chunks,
-                                       p.bucket_windows, ctx->red_a[rb ^ 1].as<XyzzDev>(), ctx->red_x[rb ^ 1].as<XyzzDev>(), flags, st));
+        HIP_OK(LaunchTe::bucket_reduce(false, ctx->red_a[rb].as<XyzzDev>(), ctx->red_x[rb].as<XyzzDev>(), n_per_win, 1u << logL, chunks,
+                                       p.bucket_windows, chunks, ctx->red_a[rb ^ 1].as<XyzzDev>(), ctx->red_x[rb ^ 1].as<XyzzDev>(), flags, st));
       else
-        HIP_OK(Launch<E>::bucket_reduce(false, ctx->red_a[rb].as<XyzzDev>(), ctx->red_x[rb].as<XyzzDev>(), n_per_win, logL, chunks,
-                                        p.bucket_windows, ctx->red_a[rb ^ 1].as<XyzzDev>(), ctx->red_x[rb ^ 1].as<XyzzDev>(), st));
+        HIP_OK(Launch<E>::bucket_reduce(false, ctx->red_a[rb].as<XyzzDev>(), ctx->red_x[rb].as<XyzzDev>(), n_per_win, 1u << logL, chunks,
+                                        p.bucket_windows, chunks, ctx->red_a[rb ^ 1].as<XyzzDev>(), ctx->red_x[rb ^ 1].as<XyzzDev>(), st));
       rb ^= 1;
     }
     HIP_OK(hipEventRecord(ev[5], st));

@@ -398,14 +398,17 @@ __global__ void __launch_bounds__(256) k_segreduce(const XyzzDevT<typename G::T>
 // Bucket -> window reduction, one level.  Per window the target is
 //     V = sum_j A_j + sum_j weight(j) * X_j,    weight(j) = j + 1 on the first level, j afterwards,
 // with X = buckets and no A on the first level.  Thread (w, t) owns chunk j in [tL, tL+L): it emits
-//     A'_t = sum A_j + sum (local weight) X_j     and     X'_t = L * sum X_j        (L = 2^logL)
+//     A'_t = sum A_j + sum (local weight) X_j     and     X'_t = L * sum X_j
 // so that V = sum_t A'_t + sum_t t * X'_t -- the same problem, L times smaller.  When one chunk is
 // left, V = A'_0.  Running sums walk the chunk from the top: run += X_j; wsum += run.
+// L need not be a power of two: the first level of a large window is cut so that its chunks fill the chip's SIMDs with exactly one
+// wave each (Plan::L0) -- 13 windows x 4096 chunks of 128 buckets are 832 waves on 1024 SIMDs, 4994 chunks of 105 are 1015; the
+// outputs of window w start at w * out_stride (a power of two for the scan that follows, the tail of a row stays empty).
 template <class G, bool FIRST>
 __global__ void __launch_bounds__(256, G::ACC_WAVES) k_bucket_reduce(const XyzzDevT<typename G::T>* __restrict__ in_a,
                                                        const XyzzDevT<typename G::T>* __restrict__ in_x,
-                                                       uint32_t n_per_win, uint32_t logL, uint32_t chunks_per_win,
-                                                       uint32_t windows, XyzzDevT<typename G::T>* __restrict__ out_a,
+                                                       uint32_t n_per_win, uint32_t L, uint32_t chunks_per_win,
+                                                       uint32_t windows, uint32_t out_stride, XyzzDevT<typename G::T>* __restrict__ out_a,
                                                        XyzzDevT<typename G::T>* __restrict__ out_x, uint32_t* __restrict__ flags) {
   using E = typename G::E;
   using XD = XyzzDevT<typename G::T>;
@@ -413,7 +416,6 @@ __global__ void __launch_bounds__(256, G::ACC_WAVES) k_bucket_reduce(const XyzzD
   if (g >= windows * chunks_per_win) return;
   typename E::Md md;
   const uint32_t w = g / chunks_per_win, t = g % chunks_per_win;
-  const uint32_t L = 1u << logL;
   const uint32_t lo = t * L;
   const uint32_t hi = (lo + L < n_per_win) ? lo + L : n_per_win;
   const XD* x = in_x + (size_t)w * n_per_win;
@@ -438,13 +440,27 @@ __global__ void __launch_bounds__(256, G::ACC_WAVES) k_bucket_reduce(const XyzzD
       if (G::CHECKS) bad |= G::failed(wsum);
     }
   }
-  G::mul_pow2(run, logL, md);
-  if (G::CHECKS) bad |= G::failed(run);
+  const size_t at = (size_t)w * out_stride + t;
   XD o;
   o.p = wsum;
-  out_a[g] = o;
+  out_a[at] = o;
+  // X'_t = L * run, most significant bit of L first: doublings, and an addition of the sum itself for every further set bit
+  if ((L & (L - 1)) == 0) {
+    G::mul_pow2(run, 31 - __builtin_clz(L), md);
+    if (G::CHECKS) bad |= G::failed(run);
+  } else {
+    const XyzzT<typename G::T> one = run;
+    for (int b = 30 - __builtin_clz(L); b >= 0; b--) {
+      G::mul_pow2(run, 1, md);
+      if (G::CHECKS) bad |= G::failed(run);
+      if ((L >> b) & 1) {
+        G::add(run, one, md);
+        if (G::CHECKS) bad |= G::failed(run);
+      }
+    }
+  }
   o.p = run;
-  out_x[g] = o;
+  out_x[at] = o;
   if (G::CHECKS && bad) flags[1] = 1;
 }
 
