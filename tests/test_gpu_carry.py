@@ -175,3 +175,27 @@ def test_golden_vectors_in_carried_chunks(ea, golden):
                 ctx.set_option("carry", carry)
                 assert ea.multi_scalar_mult(ctx, bases, scalars)[0].hex() == case["expected"], (case["curve"], case["name"], chunk, carry)
         ctx.close()
+
+
+@pytest.mark.parametrize("cid", [0, 1, 2])
+def test_first_reduce_level_with_chunks_that_fill_the_simds(ea, oracle, cid):
+    """Large windows (>= 2^17 buckets, fewer than 16 windows): the first bucket-reduce level is cut into a non-power-of-two number of
+    chunks (one wave per SIMD), X_t is scaled by a non-power-of-two L and the scan runs on padded rows -- against the oracle, with the
+    options that switch the re-cut off (explicit chunk sizes) and the recursive scheme giving the same bytes."""
+    n = 30000 if cid != 2 else 8000
+    bases = ea.generate_points(n, distinct=300, seed=40 + cid, curve=NAMES[cid])
+    sc = _scalars(cid, n, 12)
+    sc[5] = 0
+    exp = _oracle(oracle, cid, bases, sc, n)
+    ctx = ea.multi_scalar_mult_init(bases, NAMES[cid])
+    for c in (18, 19, 20, 22, 23):
+        ctx.set_option("window_bits", c)
+        assert ctx.run(sc)[0] == exp, c
+        if c in (18, 20):
+            ctx.set_option("reduce_log_chunk0", 7)      # explicit power-of-two chunks
+            assert ctx.run(sc)[0] == exp, (c, "pow2")
+            ctx.set_option("reduce_log_chunk0", 0)
+            ctx.set_option("reduce_scan", 0)            # recursive chunked scheme only
+            assert ctx.run(sc)[0] == exp, (c, "recursive")
+            ctx.set_option("reduce_scan", -1)
+    ctx.close()
