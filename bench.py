@@ -154,7 +154,9 @@ def main():
     n_ranks = args.gpus if c_sharded else world
     total_npow = args.total_npow
     if total_npow < 0:
-        total_npow = 28 if (n_ranks == 8 and args.curve == "bls12_377_g1" and args.npow == 26) else 0
+        # N = 8 defaults to BASELINE.json configs[3]: FOUR times the single-GPU problem sharded eight ways (2^28 = 8 x 2^25 at the default
+        # --npow 26).  A smaller --npow keeps the shape (2^(npow+2) over 8 GPUs) so the same code path can be rehearsed at small sizes.
+        total_npow = args.npow + 2 if (n_ranks == 8 and args.curve == "bls12_377_g1") else 0
     weak_secondary = None
     if total_npow:
         if n_ranks & (n_ranks - 1) or (1 << total_npow) < n_ranks:
@@ -234,6 +236,10 @@ def main():
         per_rank = gathered
     elif c_sharded:
         per_rank = ctx.shard_timings()
+    # everything the line needs from the headline context is read NOW: the secondary measurements below close it to hand its
+    # HBM back (round 3 queried it after the close at N = 8 and lost the line: VERDICT r3 weak #3)
+    ctx_te_path = bool(ctx.query("twisted_edwards"))
+    ctx_rccl = bool(ctx.query("rccl_exchanges")) if c_sharded else False
 
     weak_point = None
     if weak_secondary is not None:
@@ -305,7 +311,7 @@ def main():
                                 f"this library is built from {sha}")
         # the integer roofline: lane-level v_mad_u64_u32 per second in the dominant kernel against the measured
         # issue peak of 1024 SIMDs x 64 lanes / 4.3 cycles at the nominal 2.4 GHz (profiles/r01_ubench_valu_*.txt)
-        te_path = bool(ctx.query("twisted_edwards"))
+        te_path = ctx_te_path
         # v_mad_u64_u32 per mixed addition: a property of the formulas (7 multiplications of 378; 6M + 2S + one fused dual product),
         # pinned on the generated ISA by tests/test_isa.py
         mads_per_add = {0: 2646 if te_path else 3416, 1: 3542, 2: 11584}[cid]
@@ -327,15 +333,16 @@ def main():
             "dtype": "u32",
             "dtype_detail": "14 x 28-bit limbs in u32 lanes, Montgomery radix 2^392, products accumulated in u64 (v_mad_u64_u32)",
             "data": "synthetic: 2^15 distinct subgroup points replicated (reference generator shape), uniform scalars < r",
-            "config": {"workload": (f"{args.curve} MSM, 2^{total_npow} pairs sharded over {n_ranks} GPU(s) (2^{args.npow} per GPU; BASELINE.json configs[3] at N = 8), "
-                                    f"bases+scalars resident in HBM" if total_npow else
+            "config": {"workload": (f"{args.curve} MSM, 2^{total_npow} pairs sharded over {n_ranks} GPU(s) (2^{args.npow} per GPU; "
+                                    + ("BASELINE.json configs[3]" if (total_npow == 28 and n_ranks == 8) else "the shape of BASELINE.json configs[3] at another size")
+                                    + "), bases+scalars resident in HBM" if total_npow else
                                     f"{args.curve} MSM, 2^{args.npow} pairs per GPU, bases+scalars resident in HBM"),
                        "pairs_per_gpu": n, "window_bits": tm["window_bits"], "windows": tm["windows"],
                        "lane_entries": tm["lane_entries"], "precompute": bool(args.precompute),
-                       "group_law": "extended twisted Edwards (7M mixed add)" if ctx.query("twisted_edwards") else "XYZZ (8M+2S mixed add)",
+                       "group_law": "extended twisted Edwards (7M mixed add)" if ctx_te_path else "XYZZ (8M+2S mixed add)",
                        "init_s": t_init,
                        "parallelism": (f"one process, {args.gpus} shards behind the C ABI (mi355_msm_create_sharded), "
-                                       f"{'RCCL all-gather' if ctx.query('rccl_exchanges') else 'host fold'} of {args.gpus} partial points" if c_sharded else
+                                       f"{'RCCL all-gather' if ctx_rccl else 'host fold'} of {args.gpus} partial points" if c_sharded else
                                        f"{world} disjoint base/scalar slices + all-gather of {world} partial points")},
             "stage_ms_per_step": {k: v / args.steps for k, v in stage_ms.items()},
             "per_rank": per_rank,
