@@ -19,7 +19,10 @@
  * PARITY PIN: this restatement is pinned (tests/test_oracle.py) against (i) the literal constants and
  * edge-case points the reference holds, (ii) oracle/_ref: the reference's own C/C++ sources compiled here --
  * yrrid's host XYZZ curve code for BLS12-377 (CMB yrrid-ff-ec/HostCurve.cpp) and yrrid's C BLS12-381 MSM
- * (open-division/prize4-msm-wasm/yrrid/C/MSM.c) -- and (iii) the independent Python model (pymodel.py).
+ * (open-division/prize4-msm-wasm/yrrid/C/MSM.c), and the reference's blst 0.3.10 for BLS12-381 G1 AND G2
+ * (team-division/prize1-marlin-verifier/Jackytan2018/external/blst-0.3.10/blst: blst_p{1,2}s_mult_pippenger) -- the G2 template
+ * instance is thereby checked against a reference-computed G2 MSM, not only against literals -- and (iii) the independent
+ * Python model (pymodel.py).
  * The reference stores no MSM output vectors.
  */
 #include <pthread.h>
@@ -50,7 +53,7 @@ static const uint64_t P377[6] = {0x8508c00000000001ull, 0x170b5d4430000000ull, 0
 static const uint64_t P381[6] = {0xb9feffffffffaaabull, 0x1eabfffeb153ffffull, 0x6730d2a0f6b0f624ull,
                                  0x64774b84f38512bfull, 0x4b1ba7b6434bacd7ull, 0x1a0111ea397fe69aull};
 
-static field_t g_fields[2];
+static field_t g_fields[3];
 static int g_init = 0;
 
 static int fp_geq(const fp_t* a, const fp_t* b) {
@@ -179,6 +182,7 @@ static void oracle_init(void) {
   if (g_init) return;
   field_init(&g_fields[0], P377, 253, -5);
   field_init(&g_fields[1], P381, 255, -1);
+  field_init(&g_fields[2], P377, 253, -1); /* curve id 4 only: the coordinate RING of the reference's re-targeted blst copy */
   g_init = 1;
 }
 
@@ -305,24 +309,51 @@ static void fp_set_one(const field_t* f, fp_t* r) { *r = f->one; }
 #define T(name) name##_g2
 #include "jac_msm_template.inc"
 
-/* curve ids: 0 = BLS12-377 G1, 1 = BLS12-381 G1, 2 = BLS12-377 G2 (coordinates in Fp2, 200-byte Affine stride) */
+/* curve ids: 0 = BLS12-377 G1, 1 = BLS12-381 G1, 2 = BLS12-377 G2, 3 = BLS12-381 G2 (G2: coordinates in Fp2, 200-byte Affine
+ * stride; Fq2 = Fq[u]/(u^2 + 1) for BLS12-381, ARKC bls12_381/src/fields/fq2.rs:13, curve b' = 4(1 + u), curves/g2.rs:47-48) */
 static const field_t* curve_field(int curve) {
   oracle_init();
   if (curve == 0 || curve == 2) return &g_fields[0];
-  if (curve == 1) return &g_fields[1];
+  if (curve == 1 || curve == 3) return &g_fields[1];
+  if (curve == 4) return &g_fields[2];
   return NULL;
 }
+/* curve id 4 is NOT a curve of the product: the Fp2 template instance over Fp[u]/(u^2 + 1) with the BLS12-377 prime -- a ring
+ * (Fp x Fp), the structure the blst copy under /root/reference computes its "G2" in (oracle/ref_driver_blst377.c).  It exists so
+ * that the reference's G2 Pippenger, compiled here, can be compared with this template on points of one curve over that ring. */
+static int curve_is_g2(int curve) { return curve == 2 || curve == 3 || curve == 4; }
 
 int oracle_msm(int curve, const uint8_t* bases, size_t stride, const uint8_t* scalars, size_t n, uint8_t* out, int threads) {
   const field_t* f = curve_field(curve);
   if (!f) return -1;
-  return curve == 2 ? msm_impl_g2(f, bases, stride, scalars, n, out, threads) : msm_impl_g1(f, bases, stride, scalars, n, out, threads);
+  return curve_is_g2(curve) ? msm_impl_g2(f, bases, stride, scalars, n, out, threads) : msm_impl_g1(f, bases, stride, scalars, n, out, threads);
 }
 
 int oracle_msm_naive(int curve, const uint8_t* bases, size_t stride, const uint8_t* scalars, size_t n, uint8_t* out) {
   const field_t* f = curve_field(curve);
   if (!f) return -1;
-  return curve == 2 ? msm_naive_impl_g2(f, bases, stride, scalars, n, out) : msm_naive_impl_g1(f, bases, stride, scalars, n, out);
+  return curve_is_g2(curve) ? msm_naive_impl_g2(f, bases, stride, scalars, n, out) : msm_naive_impl_g1(f, bases, stride, scalars, n, out);
+}
+
+/* A Jacobian Projective image (X | Y | Z, any Z) -> the normalised image oracle_msm writes ((x, y, 1), or (1, 1, 0) for Z = 0):
+ * short_weierstrass.rs:1093-1115.  Lets tests compare with reference code that returns un-normalised triples. */
+int oracle_jac_normalize(int curve, const uint8_t* in, uint8_t* out) {
+  const field_t* f = curve_field(curve);
+  if (!f) return -1;
+  if (curve_is_g2(curve)) {
+    jac_t_g2 a;
+    memcpy(&a.x, in, 96);
+    memcpy(&a.y, in + 96, 96);
+    memcpy(&a.z, in + 192, 96);
+    jac_write_normalized_g2(f, &a, out);
+  } else {
+    jac_t_g1 a;
+    memcpy(&a.x, in, 48);
+    memcpy(&a.y, in + 48, 48);
+    memcpy(&a.z, in + 96, 48);
+    jac_write_normalized_g1(f, &a, out);
+  }
+  return 0;
 }
 
 /* Fp2 multiplication on two 96-byte Montgomery images (c0 | c1); curve 1 uses BLS12-381's Fq2 (u^2 = -1), for which the

@@ -9,7 +9,8 @@ in the Jacobian/Montgomery restatement cannot hide behind a matching error here.
 What it models (reference file:line, all under /root/reference):
   * curve constants          ARKC bls12_377/src/fields/fq.rs:4, fr.rs:24, curves/g1.rs:28-42,153-159,
                              bls12_381/src/fields/fq.rs:4, fr.rs:4, curves/g1.rs:37,69-73,
-                             bls12_377/src/fields/fq2.rs:13, curves/g2.rs:47-78
+                             bls12_377/src/fields/fq2.rs:13, curves/g2.rs:47-78,
+                             bls12_381/src/fields/fq2.rs:13, curves/g2.rs:47-48,74-91
   * Montgomery constants     SPK ff/bls12-377.hpp:10-25, ff/bls12-381.hpp:10-25 (R = 2^384, M0)
   * the MSM contract         ARK ec/src/msm/variable_base/mod.rs:68-162 (result = sum k_i * P_i,
                              truncated to the shorter slice, zero scalars skipped)
@@ -320,7 +321,37 @@ BLS12_377_G2 = Curve(
     curve_id=2,
 )
 
-CURVES = {c.name: c for c in (BLS12_377_G1, BLS12_381_G1, BLS12_377_G2)}
+# ARKC bls12_381/src/curves/g2.rs:47-48 (COEFF_B = (4, 4)), :74-91 (generator), fields/fq2.rs:13 (NONRESIDUE = -1)
+BLS12_381_G2 = Curve(
+    name="bls12_381_g2",
+    p=BLS12_381_G1.p,
+    r=BLS12_381_G1.r,
+    b=(4, 4),
+    gx=(352701069587466618187139116011060144890029952792775240219908644239793785735715026873347600343865175952761926303160,
+        3059144344244213709971259814753781636986470325476647558659373206291635324768958432433509563104347017837885763365758),
+    gy=(1985150602287291935568054521177171638300868978215655730859378665066344726373823718423869104263333984641494340347905,
+        927553665492332455747201965776037880757740193453592970025027978793976877002675564980949289727957565575433344219582),
+    ext=2,
+    nonresidue=-1,
+    curve_id=3,
+)
+
+CURVES = {c.name: c for c in (BLS12_377_G1, BLS12_381_G1, BLS12_377_G2, BLS12_381_G2)}
+
+
+def blst377_ring_curve(seed: int = 1) -> Curve:
+    """NOT a curve of the product (curve id 4 of msm_oracle.c, tests only): y^2 = x^3 + b over the RING Fp[u]/(u^2 + 1) with the
+    BLS12-377 prime -- the coordinate structure the blst copy under /root/reference computes its "G2" in (its author changed the
+    modulus to BLS12-377's and left the tower at u^2 = -1; oracle/ref_driver_blst377.c).  p = 1 mod 4, so the ring is Fp x Fp and
+    the "curve" a pair of curves over Fp; the group law holds componentwise.  The base point is a seeded random pair (x, y) and
+    b := y^2 - x^3 (the a = 0 formulas never use b); `r` only bounds the synthetic scalars."""
+    rng = random.Random(seed)
+    p = BLS12_377_G1.p
+    x = (rng.randrange(p), rng.randrange(p))
+    y = (rng.randrange(p), rng.randrange(p))
+    fx, fy = Fp2(x[0], x[1], p, -1 % p), Fp2(y[0], y[1], p, -1 % p)
+    b = fy * fy - fx * fx * fx
+    return Curve(name="blst377_ring_g2", p=p, r=BLS12_377_G1.r, b=(b.c0, b.c1), gx=x, gy=y, ext=2, nonresidue=-1, curve_id=4)
 CURVES_BY_ID = {c.curve_id: c for c in CURVES.values()}
 
 # Literal points of the FPGA harness edge-case tests (hex, normal form, BLS12-377 G1):

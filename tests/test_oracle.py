@@ -1,7 +1,10 @@
 """CPU: the oracle (C restatement of arkworks' VariableBaseMSM) against every pin we have:
 reference-held literal constants, the golden vectors (generated from pymodel and cross-checked against the reference's
 own C/C++ code at generation time), the independent Python model, and -- when oracle/_ref is present -- the reference's
-compiled HostCurve (BLS12-377) and yrrid C MSM (BLS12-381) directly."""
+compiled HostCurve (BLS12-377), yrrid C MSM (BLS12-381) and blst copy (its G1 and G2 Pippenger over the BLS12-377 prime) directly.
+The G2 legs are pinned by (i) that compiled G2 Pippenger on the coordinate ring it really computes in, (ii) the RFC 9380
+vectors the reference holds for BLS12-381 G1/G2 (P = h_eff (Q0 + Q1): an MSM whose inputs and output are reference literals),
+(iii) the reference's G2 generator / twist literals and Fq2 KATs."""
 import ctypes
 import os
 import random
@@ -46,6 +49,36 @@ def test_window_rule(oracle):
     assert [oracle.oracle_window_bits(1 << k) for k in (16, 24, 26, 28)] == [13, 18, 19, 21]
     for n in (32, 33, 1000, 65537):
         assert oracle.oracle_window_bits(n) == m.ark_window_bits(n)
+
+
+def _expand_large(case):
+    """msm_vectors_large.json: `distinct` base records replicated by doubling the vector up to n (tools/gen_golden.py)."""
+    c = m.CURVES[case["curve"]]
+    base = bytes.fromhex(case["distinct_bases"])
+    assert len(base) == case["distinct"] * c.affine_stride
+    buf = bytearray(base)
+    while len(buf) < case["n"] * c.affine_stride:
+        buf += buf[: case["n"] * c.affine_stride - len(buf)]
+    return bytes(buf), bytes.fromhex(case["scalars"])
+
+
+@pytest.fixture(scope="module")
+def golden_large():
+    import json
+
+    with open(os.path.join(ROOT, "tests", "golden", "msm_vectors_large.json")) as f:
+        return json.load(f)["cases"]
+
+
+def test_golden_vectors_large(oracle, golden_large):
+    """2^10 and 2^12 pairs on all four curves: crosses the window-rule steps c = 8 -> 9 -> 10."""
+    assert {(c["curve"], c["n"]) for c in golden_large} == {(name, n) for name in m.CURVES for n in (1 << 10, 1 << 12)}
+    for case in golden_large:
+        c = m.CURVES[case["curve"]]
+        bases, scalars = _expand_large(case)
+        out = ctypes.create_string_buffer(c.projective_bytes)
+        assert oracle.oracle_msm(c.curve_id, bases, ctypes.c_size_t(c.affine_stride), scalars, ctypes.c_size_t(case["n"]), out, 0) == 0
+        assert out.raw.hex() == case["expected"], (case["curve"], case["n"])
 
 
 def test_golden_vectors(oracle, golden):
@@ -165,6 +198,119 @@ def _check_ref381(oracle, c, n, distinct):
     assert got == c.encode_projective_normalized(ref_pt)
 
 
+BLST377 = os.path.join(ROOT, "oracle", "_ref", "libblst377.so")
+_sz = ctypes.c_size_t
+
+
+def _edge_inputs(c, n, rng, distinct):
+    """Random pairs with the cases the reference tests plant: an infinity base, a duplicated base, a base and its negation with
+    equal scalars (cancellation inside a bucket), zero and unit scalars."""
+    pts = m.random_points(c, n, rng, distinct)
+    sc = m.random_scalars(c, n, rng)
+    if n >= 16:
+        pts[3] = None
+        pts[7] = pts[8]
+        pts[9] = c.neg(pts[8])
+        sc[0], sc[1], sc[8] = 0, 1, sc[9]
+        sc[7] = sc[8]                      # equal base, equal scalar: the doubling branch inside a bucket
+    return pts, sc
+
+
+@pytest.mark.skipif(not os.path.exists(BLST377), reason="oracle/_ref not built (needs /root/reference)")
+def test_against_reference_blst_pippenger_377_g1(oracle):
+    """A full BLS12-377 G1 MSM through the reference's blst copy (blst_p1s_mult_pippenger, bindings/blst.h:238; Booth-recoded
+    windows over XYZZ buckets -- nothing in common with arkworks' algorithm) at 2^4 ... 2^14."""
+    ref = ctypes.CDLL(BLST377)
+    c = m.BLS12_377_G1
+    rng = random.Random(0xB157)
+    for n in (1, 2, 16, 257, 1 << 10, 1 << 12, 1 << 14):
+        pts, sc = _edge_inputs(c, n, rng, min(n, 96))
+        bases, scal = c.encode_affine_array(pts), m.encode_scalars(sc)
+        raw, got = ctypes.create_string_buffer(144), ctypes.create_string_buffer(144)
+        ref.refblst_g1_msm(bases, _sz(104), scal, _sz(n), _sz(253), raw)
+        assert oracle.oracle_jac_normalize(0, raw, got) == 0
+        assert got.raw == oracle_msm(oracle, 0, bases, scal, n), n
+    # its field multiplication is the BLS12-377 one (the copy's modulus was changed by its author: consts.c:27-35)
+    for _ in range(100):
+        a, b = rng.randrange(c.p), rng.randrange(c.p)
+        o1, o2 = ctypes.create_string_buffer(48), ctypes.create_string_buffer(48)
+        oracle.oracle_fp_mul(0, a.to_bytes(48, "little"), b.to_bytes(48, "little"), o1)
+        ref.refblst_fp_mul(a.to_bytes(48, "little"), b.to_bytes(48, "little"), o2)
+        assert o1.raw == o2.raw
+
+
+@pytest.mark.skipif(not os.path.exists(BLST377), reason="oracle/_ref not built (needs /root/reference)")
+def test_g2_template_against_reference_blst_g2_pippenger(oracle):
+    """The G2 leg of the oracle against a REFERENCE COMPUTATION: blst_p2s_mult_pippenger (bindings/blst.h:262, src/e2.c,
+    src/multi_scalar.c) compiled from the reference tree.  That copy computes over Fp[u]/(u^2 + 1) with the BLS12-377 prime
+    (oracle/ref_driver_blst377.c explains why) -- a ring, on which the group law still holds for points of one curve -- so the
+    oracle's Fp2 template is instantiated over the same structure (curve id 4) and must agree, 2^0 ... 2^12 pairs with infinity,
+    duplicate and negated bases.  Everything but the constant beta is shared with the BLS12-377 / BLS12-381 G2 instances."""
+    ref = ctypes.CDLL(BLST377)
+    c = m.blst377_ring_curve(3)
+    assert c.on_curve(c.generator())
+    rng = random.Random(0xB252)
+    for n in (1, 2, 16, 64, 257, 1 << 10, 1 << 12):
+        pts, sc = _edge_inputs(c, n, rng, min(n, 48))
+        bases, scal = c.encode_affine_array(pts), m.encode_scalars(sc)
+        raw, got, exp = (ctypes.create_string_buffer(288) for _ in range(3))
+        ref.refblst_g2_msm(bases, _sz(200), scal, _sz(n), _sz(253), raw)
+        assert oracle.oracle_jac_normalize(4, raw, got) == 0
+        assert oracle.oracle_msm(4, bases, _sz(200), scal, _sz(n), exp, 0) == 0
+        assert got.raw == exp.raw, n
+        if n <= 64:
+            assert exp.raw == c.encode_projective_normalized(c.msm_naive(pts, sc)), n
+    p = c.p
+    for _ in range(100):   # blst's Fp2 product (u^2 = -1) == the oracle's Karatsuba with beta = -1
+        a = b"".join(rng.randrange(p).to_bytes(48, "little") for _ in range(2))
+        b = b"".join(rng.randrange(p).to_bytes(48, "little") for _ in range(2))
+        o1, o2 = ctypes.create_string_buffer(96), ctypes.create_string_buffer(96)
+        assert oracle.oracle_fp2_mul(4, a, b, o1) == 0
+        ref.refblst_fp2_mul(a, b, o2)
+        assert o1.raw == o2.raw
+
+
+def _h2c_point(curve, rec):
+    if curve.ext == 1:
+        return (int(rec["x"], 16), int(rec["y"], 16))
+    xs, ys = rec["x"].split(","), rec["y"].split(",")
+    return (curve.F((int(xs[0], 16), int(xs[1], 16))), curve.F((int(ys[0], 16), int(ys[1], 16))))
+
+
+@pytest.mark.parametrize("group,name", [("g1", "bls12_381_g1"), ("g2", "bls12_381_g2")])
+def test_rfc9380_vectors_held_by_the_reference(oracle, group, name):
+    """Reference-held known answers for BLS12-381 G1 AND G2 (ARK ec/src/hashing/tests/testdata/*.json, tools/extract_h2c_kat.py):
+    P = h_eff (Q0 + Q1).  h_eff = sum_j h_j 2^(212 j), so the MSM over the bases 2^(212 j) Q0, 2^(212 j) Q1 with scalars h_j, h_j
+    must give the literal P -- through the C oracle (Pippenger and naive) and through the Python model.  Q0, Q1 are curve points
+    outside the order-r subgroup: arkworks' msm is exact for those too."""
+    import json
+
+    kat = json.load(open(os.path.join(ROOT, "tests", "golden", "h2c_kat_bls12_381.json")))
+    c = m.CURVES[name]
+    chunks = [int(h, 16) for h in kat[group]["h_eff_chunks"]]
+    shift = kat["chunk_bits"]
+    assert sum(h << (shift * j) for j, h in enumerate(chunks)) == int(kat[group]["h_eff"], 16)
+    all_pts, all_sc, total = [], [], None
+    for v in kat[group]["vectors"]:
+        q0, q1, P = (_h2c_point(c, v[k]) for k in ("Q0", "Q1", "P"))
+        pts, sc = [], []
+        for j, h in enumerate(chunks):
+            pts += [c.mul(1 << (shift * j), q0), c.mul(1 << (shift * j), q1)]
+            sc += [h, h]
+        bases, scal = c.encode_affine_array(pts), m.encode_scalars(sc)
+        out, outn = ctypes.create_string_buffer(c.projective_bytes), ctypes.create_string_buffer(c.projective_bytes)
+        assert oracle.oracle_msm(c.curve_id, bases, _sz(c.affine_stride), scal, _sz(len(pts)), out, 0) == 0
+        assert oracle.oracle_msm_naive(c.curve_id, bases, _sz(c.affine_stride), scal, _sz(len(pts)), outn) == 0
+        assert out.raw == outn.raw == c.encode_projective_normalized(P), v["msg"]
+        all_pts += pts
+        all_sc += sc
+        total = c.add(total, P)
+    # all five vectors as ONE msm (30 pairs for G2): the sum of the five literal outputs
+    out = ctypes.create_string_buffer(c.projective_bytes)
+    assert oracle.oracle_msm(c.curve_id, c.encode_affine_array(all_pts), _sz(c.affine_stride), m.encode_scalars(all_sc), _sz(len(all_pts)), out, 0) == 0
+    assert out.raw == c.encode_projective_normalized(total)
+
+
 # ---- G2 / Fp2 ---------------------------------------------------------------------------------------------------
 
 def test_fq2_known_answers_from_reference(oracle):
@@ -193,10 +339,11 @@ def test_fq2_known_answers_from_reference(oracle):
         assert [r.c0, r.c1] == [int(x) for x in c["out"]]
 
 
-def test_g2_oracle_vs_model():
-    """BLS12-377 G2 (Fq2 = Fq[u]/(u^2+5), b' = (0, 1551...906): ARKC bls12_377/src/fields/fq2.rs:13, curves/g2.rs:47-78)."""
+@pytest.mark.parametrize("c", [m.BLS12_377_G2, m.BLS12_381_G2], ids=lambda c: c.name)
+def test_g2_oracle_vs_model(c):
+    """BLS12-377 G2 (Fq2 = Fq[u]/(u^2+5), b' = (0, 1551...906): ARKC bls12_377/src/fields/fq2.rs:13, curves/g2.rs:47-78) and
+    BLS12-381 G2 (u^2 = -1, b' = (4, 4): ARKC bls12_381/src/fields/fq2.rs:13, curves/g2.rs:47-48,74-91)."""
     lib = ctypes.CDLL(os.path.join(ROOT, "oracle", "liboracle.so"))
-    c = m.BLS12_377_G2
     g = c.generator()
     assert c.on_curve(g) and c.mul(c.r, g) is None
     rng = random.Random(2)
@@ -206,21 +353,23 @@ def test_g2_oracle_vs_model():
         if n > 4:
             sc[1], sc[2], pts[3] = 0, 1, None
         out = ctypes.create_string_buffer(288)
-        assert lib.oracle_msm(2, c.encode_affine_array(pts), ctypes.c_size_t(200), m.encode_scalars(sc), ctypes.c_size_t(n), out, 0) == 0
+        assert lib.oracle_msm(c.curve_id, c.encode_affine_array(pts), ctypes.c_size_t(200), m.encode_scalars(sc), ctypes.c_size_t(n), out, 0) == 0
         assert out.raw == c.encode_projective_normalized(c.msm_pippenger(pts, sc) if n > 40 else c.msm_naive(pts, sc)), n
 
 
-def test_g2_generator_and_twist_literals_pin_the_g2_oracle(golden_constants):
-    """The reference's own G2 literals (tests/golden/constants.json "bls12_377_g2", extracted from
-    ARKC bls12_377/src/curves/g2.rs:47-50, 61-78 and fields/fq2.rs:13): the generator satisfies y^2 = x^3 + b' over
-    Fq[u]/(u^2 + 5) and has order r -- checked in the Python model AND through the C oracle's own Fq2 arithmetic
-    (r * G = O and (r - 1) * G = -G via oracle_msm), so the G2 oracle is pinned to reference data, not only to pymodel."""
-    k = golden_constants["bls12_377_g2"]
-    c = m.BLS12_377_G2
+@pytest.mark.parametrize("c", [m.BLS12_377_G2, m.BLS12_381_G2], ids=lambda c: c.name)
+def test_g2_generator_and_twist_literals_pin_the_g2_oracle(golden_constants, c):
+    """The reference's own G2 literals (tests/golden/constants.json "bls12_377_g2" / "bls12_381_g2", extracted from
+    ARKC bls12_377/src/curves/g2.rs:47-50, 61-78, fields/fq2.rs:13 and bls12_381/src/curves/g2.rs:47-48, 74-91, fields/fq2.rs:13):
+    the generator satisfies y^2 = x^3 + b' over Fq[u]/(u^2 - beta) and has order r -- checked in the Python model AND through the
+    C oracle's own Fq2 arithmetic (r * G = O and (r - 1) * G = -G via oracle_msm), so the G2 oracle is pinned to reference data,
+    not only to pymodel."""
+    k = golden_constants[c.name]
     gx, gy = (int(k["GX0"]), int(k["GX1"])), (int(k["GY0"]), int(k["GY1"]))
     assert (gx, gy) == (tuple(c.gx), tuple(c.gy)) and tuple(c.b) == (int(k["B0"]), int(k["B1"])) and c.nonresidue == int(k["NONRESIDUE"])
     p = c.p
-    X, Y, B = m.Fp2(gx[0], gx[1], p, p - 5), m.Fp2(gy[0], gy[1], p, p - 5), m.Fp2(int(k["B0"]), int(k["B1"]), p, p - 5)
+    nr = int(k["NONRESIDUE"]) % p
+    X, Y, B = m.Fp2(gx[0], gx[1], p, nr), m.Fp2(gy[0], gy[1], p, nr), m.Fp2(int(k["B0"]), int(k["B1"]), p, nr)
     assert Y * Y == X * X * X + B                                  # on the twist E'(Fq2)
     G = c.generator()
     assert c.on_curve(G) and c.mul(c.r, G) is None                 # in the order-r subgroup (ARK test-templates/src/lib.rs:42-47)
@@ -228,5 +377,5 @@ def test_g2_generator_and_twist_literals_pin_the_g2_oracle(golden_constants):
     base = c.encode_affine_array([G])
     for scalar, expect in ((c.r, None), (c.r - 1, c.neg(G)), (1, G)):
         out = ctypes.create_string_buffer(288)
-        assert lib.oracle_msm(2, base, ctypes.c_size_t(200), m.encode_scalars([scalar]), ctypes.c_size_t(1), out, 0) == 0
+        assert lib.oracle_msm(c.curve_id, base, ctypes.c_size_t(200), m.encode_scalars([scalar]), ctypes.c_size_t(1), out, 0) == 0
         assert out.raw == c.encode_projective_normalized(expect), scalar

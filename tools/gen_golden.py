@@ -6,7 +6,14 @@ from /root/reference, before writing):   python tools/gen_golden.py
 
 Vectors are data only: inputs as the byte images the FFI passes (hex), expected output as the normalised 144-byte
 projective image (hex).  Expected values come from oracle/pymodel.py (affine big-int arithmetic) and are asserted
-equal to (a) the reference HostCurve naive MSM for BLS12-377 and (b) the reference yrrid C MSM for BLS12-381.
+equal to (a) the reference HostCurve naive MSM AND the reference's blst copy (its Pippenger, re-targeted by its author to the
+BLS12-377 prime: oracle/ref_driver_blst377.c) for BLS12-377 G1, (b) the reference yrrid C MSM for BLS12-381 G1.  G2 vectors are
+asserted equal to the C oracle, whose Fp2 template instance is itself checked against the reference's compiled G2 Pippenger
+(tests/test_oracle.py) and, for BLS12-381, against the RFC 9380 vectors the reference holds (tests/golden/h2c_kat_bls12_381.json).
+
+msm_vectors_large.json (sizes 2^10 and 2^12, SURVEY 8c "sizes 2^4 ... 2^12") keeps the FFI images compact: the `distinct` base
+records once (the test replicates them by doubling the vector, exactly what the reference generator does: P1A
+yrrid/src/util.rs:15-28) and every scalar explicitly.
 """
 import ctypes
 import json
@@ -30,6 +37,25 @@ def ref377(curve, pts, sc):
     inf = lib.ref377_msm_naive(curve.encode_affine_array(pts), ctypes.c_size_t(104), m.encode_scalars(sc),
                                ctypes.c_size_t(len(pts)), out)
     return curve.encode_projective_normalized(None) if inf else out.raw
+
+
+def blst377(curve, pts, sc):
+    """BLS12-377 G1 through the reference's blst Pippenger (raw Jacobian out, normalised by the C oracle's to-affine)."""
+    sz = ctypes.c_size_t
+    lib = ctypes.CDLL(os.path.join(ROOT, "oracle", "_ref", "libblst377.so"))
+    orc = ctypes.CDLL(os.path.join(ROOT, "oracle", "liboracle.so"))
+    raw, out = ctypes.create_string_buffer(144), ctypes.create_string_buffer(144)
+    lib.refblst_g1_msm(curve.encode_affine_array(pts), sz(104), m.encode_scalars(sc), sz(len(pts)), sz(253), raw)
+    assert orc.oracle_jac_normalize(0, raw, out) == 0
+    return out.raw
+
+
+def oracle_c(curve, bases: bytes, scalars: bytes, n):
+    sz = ctypes.c_size_t
+    orc = ctypes.CDLL(os.path.join(ROOT, "oracle", "liboracle.so"))
+    out = ctypes.create_string_buffer(curve.projective_bytes)
+    assert orc.oracle_msm(curve.curve_id, bases, sz(curve.affine_stride), scalars, sz(n), out, 0) == 0
+    return out.raw
 
 
 def ref381(curve, pts, sc):
@@ -59,10 +85,13 @@ def case(name, curve, pts, sc, note, zero_style="0.4", check_ref=True):
     if check_ref:
         if curve.curve_id == 0:
             assert ref377(curve, pts, sc) == exp, name
+            if all(k < (1 << 253) for k in sc):
+                assert blst377(curve, pts, sc) == exp, name
         elif all(k < (1 << 255) for k in sc) and exp != curve.encode_projective_normalized(None):
             # (the reference binary has no printable form for an infinite result)
             r = ref381(curve, pts, sc)
             assert r is None or r == exp, name
+    assert oracle_c(curve, curve.encode_affine_array(pts, zero_style), m.encode_scalars(sc), len(pts)) == exp, name
     return {"name": name, "curve": curve.name, "note": note, "n": len(pts),
             "bases": curve.encode_affine_array(pts, zero_style).hex(), "scalars": m.encode_scalars(sc).hex(),
             "expected": exp.hex()}
@@ -126,9 +155,64 @@ def main():
     gg = g2.generator()
     cases.append(case("alternating_pm_generator", g2, [gg if i % 2 == 0 else g2.neg(gg) for i in range(16)], [sc[6]] * 16,
                       "G2: +G, -G with one scalar -> infinity", check_ref=False))
+    # BLS12-381 G2 (Fq2 = Fq[u]/(u^2 + 1), b' = 4(1 + u): ARKC bls12_381/src/curves/g2.rs:47-48, fields/fq2.rs:13)
+    h2 = m.BLS12_381_G2
+    rng = random.Random(0xC0FFEE + 3)
+    for n, distinct in ((1, 1), (5, 3), (33, 8), (100, 10)):
+        pts = m.random_points(h2, n, rng, distinct)
+        sc = m.random_scalars(h2, n, rng)
+        cases.append(case(f"random_n{n}", h2, pts, sc, "381 G2: uniform scalars < r; replicated bases", check_ref=False))
+    pts = m.random_points(h2, 24, rng, 4)
+    sc = m.random_scalars(h2, 24, rng)
+    sc[0], sc[1], sc[2] = 0, 1, h2.r - 1
+    pts[5] = None
+    cases.append(case("special_scalars_and_infinity", h2, pts, sc, "381 G2: 0, 1, r-1 scalars and an infinity base", check_ref=False))
+    gg = h2.generator()
+    cases.append(case("alternating_pm_generator", h2, [gg if i % 2 == 0 else h2.neg(gg) for i in range(16)], [sc[6]] * 16,
+                      "381 G2: +G, -G with one scalar -> infinity", check_ref=False))
     with open(os.path.join(OUT, "msm_vectors.json"), "w") as f:
         json.dump({"generator": "tools/gen_golden.py", "cases": cases}, f, indent=0)
     print("wrote", len(cases), "cases")
+
+    # ---- sizes 2^10 and 2^12: every curve, compact images, cross-checked against everything that can run them ---------------
+    large = []
+    for curve in (m.BLS12_377_G1, m.BLS12_381_G1, m.BLS12_377_G2, m.BLS12_381_G2):
+        for npow, distinct in ((10, 64), (12, 128)):
+            n = 1 << npow
+            rng = random.Random(0xB16 + 16 * curve.curve_id + npow)
+            base = m.random_points(curve, distinct, rng, distinct)
+            base[5] = None                                  # an infinity base (replicated n / distinct times)
+            base[9] = curve.neg(base[8])                    # a base and its negation meet in buckets
+            pts = list(base)
+            while len(pts) < n:
+                pts.extend(pts[: n - len(pts)])
+            sc = m.random_scalars(curve, n, rng)
+            sc[0], sc[1], sc[2], sc[3] = 0, 1, curve.r - 1, 2
+            sc[8 + distinct] = sc[8]                         # equal scalars on equal bases: the doubling branch of a bucket add
+            exp = curve.encode_projective_normalized(curve.msm_pippenger(pts, sc))
+            bases_img, scal_img = curve.encode_affine_array(pts), m.encode_scalars(sc)
+            assert oracle_c(curve, bases_img, scal_img, n) == exp, (curve.name, n)
+            checked = ["pymodel.msm_pippenger", "oracle/msm_oracle.c"]
+            if curve.curve_id == 0:
+                assert blst377(curve, pts, sc) == exp
+                checked.append("oracle/_ref/libblst377.so (reference blst Pippenger)")
+                if npow == 10:
+                    assert ref377(curve, pts, sc) == exp
+                    checked.append("oracle/_ref/libref377.so (reference HostCurve, naive)")
+            if curve.curve_id == 1:
+                # the reference binary has no infinity input form: run it on the finite pairs only (the dropped ones add nothing)
+                keep = [i for i in range(n) if pts[i] is not None]
+                r = ref381(curve, [pts[i] for i in keep], [sc[i] for i in keep])
+                assert r == exp
+                checked.append("oracle/_ref/yrrid381_msm (reference C MSM)")
+            large.append({"name": f"large_2^{npow}", "curve": curve.name, "n": n, "distinct": distinct,
+                          "note": "bases = the `distinct` records replicated by doubling the vector up to n (P1A yrrid/src/util.rs:15-28); "
+                                  "record 5 is infinity, record 9 = -record 8; scalars 0, 1, r-1, 2 lead",
+                          "distinct_bases": curve.encode_affine_array(base).hex(), "scalars": scal_img.hex(), "expected": exp.hex(),
+                          "checked_against": checked})
+            print("large", curve.name, n, "ok:", ", ".join(checked), flush=True)
+    with open(os.path.join(OUT, "msm_vectors_large.json"), "w") as f:
+        json.dump({"generator": "tools/gen_golden.py", "cases": large}, f, indent=0)
 
     # literal constants the reference holds (data, not code)
     consts = {
@@ -151,8 +235,14 @@ def main():
             "GX": str(m.BLS12_381_G1.gx), "GY": str(m.BLS12_381_G1.gy), "B": 4,
         },
     }
-    with open(os.path.join(OUT, "constants.json"), "w") as f:
+    cpath = os.path.join(OUT, "constants.json")
+    if os.path.exists(cpath):   # keep what tools/extract_g2_consts.py added (G2 literals)
+        old = json.load(open(cpath))
+        for k, v in old.items():
+            consts.setdefault(k, v)
+    with open(cpath, "w") as f:
         json.dump(consts, f, indent=1)
+        f.write("\n")
 
 
 if __name__ == "__main__":
