@@ -37,7 +37,7 @@ def hipcc() -> str:
     raise RuntimeError("hipcc not found: the MSM engine is HIP-only (no CPU fallback)")
 
 
-ENGINE_UNITS = ["msm_engine.hip", "partition.hip", "kernels_377g1.hip", "kernels_381g1.hip", "kernels_377g2.hip", "kernels_377te.hip"]
+ENGINE_UNITS = ["msm_engine.hip", "partition.hip", "kernels_377g1.hip", "kernels_381g1.hip", "kernels_377g2.hip", "kernels_381g2.hip", "kernels_377te.hip"]
 
 
 def build_engine(force: bool = False) -> str:

@@ -90,8 +90,8 @@ extern "C" {
 
 // words per input / output record of `op` on `curve` (0/0 for an op the curve does not have)
 int msm_devtest_shape(int curve, int op, int* in_words, int* out_words) {
-  if (!in_words || !out_words || curve < 0 || curve > 2) return -1;
-  msm::devtest_shape(op, curve == 2 ? 2 * msm::NL : msm::NL, *in_words, *out_words);
+  if (!in_words || !out_words || curve < 0 || curve > 3) return -1;
+  msm::devtest_shape(op, curve >= 2 ? 2 * msm::NL : msm::NL, *in_words, *out_words);
   if (curve != 0 && op >= msm::DT_TE_MADD && op <= msm::DT_TE_DBL) *in_words = *out_words = 0;
   if (curve != 0 && op == msm::DT_TE_ADD_QUAD) *in_words = *out_words = 0;
   return (*in_words) ? 0 : -1;
@@ -111,7 +111,8 @@ int msm_devtest_run(int curve, int op, const uint32_t* in, uint32_t* out, size_t
     switch (curve) {
       case 0: e = msm::launch_op<msm::Bls12_377_G1, true>(op, d_in, iw, d_out, ow, (uint32_t)n); break;
       case 1: e = msm::launch_op<msm::Bls12_381_G1, false>(op, d_in, iw, d_out, ow, (uint32_t)n); break;
-      default: e = msm::launch_op<msm::Bls12_377_G2, false>(op, d_in, iw, d_out, ow, (uint32_t)n); break;
+      case 2: e = msm::launch_op<msm::Bls12_377_G2, false>(op, d_in, iw, d_out, ow, (uint32_t)n); break;
+      default: e = msm::launch_op<msm::Bls12_381_G2, false>(op, d_in, iw, d_out, ow, (uint32_t)n); break;
     }
   }
   if (e == hipSuccess) e = hipDeviceSynchronize();

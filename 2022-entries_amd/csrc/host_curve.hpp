@@ -103,6 +103,15 @@ struct Bls12_377_G2 {
     fe_set(g.y.c0, Bls12_377_Fq::G2Y0); fe_set(g.y.c1, Bls12_377_Fq::G2Y1);
   }
 };
+struct Bls12_381_G2 {   // Fq2 = Fq[u]/(u^2 + 1): ARKC bls12_381/src/fields/fq2.rs:13; generator curves/g2.rs:74-91
+  using E = Fp2El<Bls12_381_Fq, 1>;
+  using FR = Bls12_381_Fr;
+  static constexpr int SCALAR_BITS = 255;
+  static void generator(AffineT<Fe2>& g) {
+    fe_set(g.x.c0, Bls12_381_Fq::G2X0); fe_set(g.x.c1, Bls12_381_Fq::G2X1);
+    fe_set(g.y.c0, Bls12_381_Fq::G2Y0); fe_set(g.y.c1, Bls12_381_Fq::G2Y1);
+  }
+};
 
 // Synthetic input generator in the shape of the reference harness (P1A yrrid/src/util.rs:15-28,
 // 6block/src/util.rs:15-29): `distinct` subgroup points P_j = (h0 + j*h1) * G, batch-normalised to affine

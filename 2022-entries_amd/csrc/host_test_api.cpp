@@ -238,6 +238,7 @@ static int te_finish_host(uint8_t* out, const Xyzz& acc, const Modulus<TF>& md) 
     case 0: fn<Bls12_377_G1>(__VA_ARGS__); return 0;      \
     case 1: fn<Bls12_381_G1>(__VA_ARGS__); return 0;      \
     case 2: fn<Bls12_377_G2>(__VA_ARGS__); return 0;      \
+    case 3: fn<Bls12_381_G2>(__VA_ARGS__); return 0;      \
     default: return -1;                                   \
   }
 
@@ -433,6 +434,7 @@ extern "C" int ht_fold_both(int curve, const uint8_t* pts, size_t stride, const 
                             uint8_t* out_generic, uint8_t* out_fold64) {
   if (curve == 1) return te ? 1 : t_fold_both<Bls12_381_G1>(pts, stride, mult, windows, c, 0, out_generic, out_fold64);
   if (curve == 2) return te ? 1 : t_fold_both<Bls12_377_G2>(pts, stride, mult, windows, c, 0, out_generic, out_fold64);
+  if (curve == 3) return te ? 1 : t_fold_both<Bls12_381_G2>(pts, stride, mult, windows, c, 0, out_generic, out_fold64);
   return t_fold_both<Bls12_377_G1>(pts, stride, mult, windows, c, te, out_generic, out_fold64);
 }
 
@@ -484,19 +486,20 @@ static int t_devop(int op, const uint32_t* in, int iw, uint32_t* out, int ow, si
 
 extern "C" int ht_devop(int curve, int op, const uint32_t* in, uint32_t* out, size_t n) {
   int iw = 0, ow = 0;
-  if (curve < 0 || curve > 2 || !in || !out) return -1;
-  devtest_shape(op, curve == 2 ? 2 * NL : NL, iw, ow);
+  if (curve < 0 || curve > 3 || !in || !out) return -1;
+  devtest_shape(op, curve >= 2 ? 2 * NL : NL, iw, ow);
   if (!iw) return -1;
   switch (curve) {
     case 0: return t_devop<Bls12_377_G1, true>(op, in, iw, out, ow, n);
     case 1: return t_devop<Bls12_381_G1, false>(op, in, iw, out, ow, n);
-    default: return t_devop<Bls12_377_G2, false>(op, in, iw, out, ow, n);
+    case 2: return t_devop<Bls12_377_G2, false>(op, in, iw, out, ow, n);
+    default: return t_devop<Bls12_381_G2, false>(op, in, iw, out, ow, n);
   }
 }
 
 extern "C" int ht_devop_shape(int curve, int op, int* in_words, int* out_words) {
-  if (!in_words || !out_words || curve < 0 || curve > 2) return -1;
-  devtest_shape(op, curve == 2 ? 2 * NL : NL, *in_words, *out_words);
+  if (!in_words || !out_words || curve < 0 || curve > 3) return -1;
+  devtest_shape(op, curve >= 2 ? 2 * NL : NL, *in_words, *out_words);
   if (curve != 0 && ((op >= DT_TE_MADD && op <= DT_TE_DBL) || op == DT_TE_ADD_QUAD)) *in_words = *out_words = 0;
   return (*in_words) ? 0 : -1;
 }

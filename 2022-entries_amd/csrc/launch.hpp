@@ -61,5 +61,6 @@ struct PartLaunch {
 extern template struct Launch<Bls12_377_G1::E>;
 extern template struct Launch<Bls12_381_G1::E>;
 extern template struct Launch<Bls12_377_G2::E>;
+extern template struct Launch<Bls12_381_G2::E>;
 
 }  // namespace msm

@@ -58,6 +58,10 @@ using HipFailure = msm_host::PipelineError;
 
 RustError ok() { return RustError{0, nullptr}; }
 
+// coordinates in Fq2 (two limb vectors per coordinate) / scalars modulo the BLS12-381 group order
+inline bool is_g2(int curve) { return curve == MI355_BLS12_377_G2 || curve == MI355_BLS12_381_G2; }
+inline bool is_381(int curve) { return curve == MI355_BLS12_381_G1 || curve == MI355_BLS12_381_G2; }
+
 RustError fail(int code, const char* msg) {
   RustError e;
   e.code = code ? code : -1;
@@ -233,7 +237,7 @@ struct mi355_msm_ctx {
   float last_ms[MI355_T_COUNT] = {};
   uint64_t last_info[8] = {};
 
-  int scalar_bits() const { return curve == MI355_BLS12_381_G1 ? 255 : 253; }
+  int scalar_bits() const { return (curve == MI355_BLS12_381_G1 || curve == MI355_BLS12_381_G2) ? 255 : 253; }
 
   // use_tables = false plans the run WITHOUT the precomputed tables of this context (the XYZZ fallback of a
   // twisted-Edwards context, whose short-Weierstrass tables were dropped)
@@ -409,7 +413,7 @@ size_t fit_chunk(mi355_msm_ctx* ctx, size_t want, bool use_tables, uint32_t forc
   for (size_t i = 0; i < nb; i++) held += wb[i]->bytes;
   uint64_t avail = (uint64_t)free_b + held;
   if (ctx->opt_mem_limit > 0 && (uint64_t)ctx->opt_mem_limit < avail) avail = (uint64_t)ctx->opt_mem_limit;
-  const uint64_t el = ctx->curve == MI355_BLS12_377_G2 ? 2 : 1;
+  const uint64_t el = is_g2(ctx->curve) ? 2 : 1;
   size_t cn = want;
   while (cn > 1024) {
     const Plan p = ctx->plan(cn, use_tables, force_c);
@@ -436,11 +440,12 @@ void with_curve(int curve, Fn&& fn) {
     case MI355_BLS12_377_G1: fn.template operator()<Bls12_377_G1>(); break;
     case MI355_BLS12_381_G1: fn.template operator()<Bls12_381_G1>(); break;
     case MI355_BLS12_377_G2: fn.template operator()<Bls12_377_G2>(); break;
+    case MI355_BLS12_381_G2: fn.template operator()<Bls12_381_G2>(); break;
     default: bad_arg("unknown curve id %d", curve);
   }
 }
-bool known_curve(int c) { return c == MI355_BLS12_377_G1 || c == MI355_BLS12_381_G1 || c == MI355_BLS12_377_G2; }
-size_t coord_bytes(int curve) { return curve == MI355_BLS12_377_G2 ? 96 : 48; }
+bool known_curve(int c) { return c >= MI355_BLS12_377_G1 && c <= MI355_BLS12_381_G2; }
+size_t coord_bytes(int curve) { return is_g2(curve) ? 96 : 48; }
 
 template <class C>
 void convert_bases(mi355_msm_ctx* ctx, const uint8_t* d_raw, size_t n, size_t stride, hipStream_t st) {
@@ -687,7 +692,7 @@ bool run_chunk_impl(mi355_msm_ctx* ctx, const uint32_t* d_scalars, size_t base0,
   gb.counts = ctx->part_counts.as<uint32_t>();
   gb.totals = ctx->part_totals.as<uint32_t>();
   hipError_t gerr = hipSuccess;
-  const int sorted = PartLaunch::run(ctx->curve == MI355_BLS12_381_G1 ? 1 : 0, ctx->opt_scalars_montgomery != 0, d_scalars, inf, gp, gb, st,
+  const int sorted = PartLaunch::run((ctx->curve == MI355_BLS12_381_G1 || ctx->curve == MI355_BLS12_381_G2) ? 1 : 0, ctx->opt_scalars_montgomery != 0, d_scalars, inf, gp, gb, st,
                                      ev[1], gerr);
   HIP_OK(gerr);
   const uint2* entries = gb.entries[sorted];
@@ -1580,7 +1585,7 @@ RustError mi355_msm_plan(int curve, size_t npoints, int precompute, const long* 
     }
     uint64_t reduce_levels = 1;
     for (uint32_t chunks = p.T0; chunks > 1; chunks = ceil_div(chunks, 1u << p.logL)) reduce_levels++;
-    const uint64_t el = (curve == MI355_BLS12_377_G2) ? 2 : 1;
+    const uint64_t el = is_g2(curve) ? 2 : 1;
     out[0] = p.c;
     out[1] = p.windows;
     out[2] = p.bucket_windows;

@@ -66,7 +66,7 @@ inline U256 fr_add(U256 a, U256 b, const U256& r) {
   return s;
 }
 inline U256 fr_modulus(int curve) {
-  const uint32_t* r = (curve == MI355_BLS12_381_G1) ? msm::Bls12_381_Fr::R : msm::Bls12_377_Fr::R;
+  const uint32_t* r = is_381(curve) ? msm::Bls12_381_Fr::R : msm::Bls12_377_Fr::R;
   U256 m;
   for (int i = 0; i < 4; i++) m.w[i] = (uint64_t)r[2 * i] | ((uint64_t)r[2 * i + 1] << 32);
   return m;

@@ -23,11 +23,11 @@ import ctypes
 import os
 from typing import List, Optional, Sequence
 
-CURVE_IDS = {"bls12_377_g1": 0, "bls12_381_g1": 1, "bls12_377_g2": 2}
+CURVE_IDS = {"bls12_377_g1": 0, "bls12_381_g1": 1, "bls12_377_g2": 2, "bls12_381_g2": 3}
 AFFINE_STRIDE = 104          # size_of::<G1Affine>()
 SCALAR_BYTES = 32
 PROJECTIVE_BYTES = 144       # size_of::<G1Projective>()
-_COORD_BYTES = {0: 48, 1: 48, 2: 96}   # G2 coordinates live in Fq2 (c0 | c1)
+_COORD_BYTES = {0: 48, 1: 48, 2: 96, 3: 96}   # G2 coordinates live in Fq2 (c0 | c1)
 
 
 def affine_stride(curve) -> int:

@@ -46,8 +46,10 @@ typedef struct mi355_msm_ctx mi355_msm_ctx;
 enum {
   MI355_BLS12_377_G1 = 0, /* fq: ARKC bls12_377/src/fields/fq.rs:4, curve b = 1 */
   MI355_BLS12_381_G1 = 1, /* fq: ARKC bls12_381/src/fields/fq.rs:4, curve b = 4 */
-  MI355_BLS12_377_G2 = 2  /* coordinates in Fq2 = Fq[u]/(u^2+5) (ARKC bls12_377/src/fields/fq2.rs:13, curves/g2.rs:47-78):
+  MI355_BLS12_377_G2 = 2, /* coordinates in Fq2 = Fq[u]/(u^2+5) (ARKC bls12_377/src/fields/fq2.rs:13, curves/g2.rs:47-78):
                              Affine images are 200 B (x.c0 x.c1 y.c0 y.c1, flag at byte 192), Projective images 288 B */
+  MI355_BLS12_381_G2 = 3  /* Fq2 = Fq[u]/(u^2+1), b' = 4(1+u) (ARKC bls12_381/src/fields/fq2.rs:13, curves/g2.rs:47-48, 74-91);
+                             same images as MI355_BLS12_377_G2 */
 };
 
 /* Stage indices of mi355_msm_last_timings(). */

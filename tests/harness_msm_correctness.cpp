@@ -1,7 +1,9 @@
 // C++ restatement of the reference's `msm_correctness` test (P1A combined-top-solutions/tests/msm.rs:15-40) against the
 // harness-named FFI (include/mi355_msm_shims.h) and the C++ mirror of the Rust operator API (include/mi355_msm.hpp):
 // generate points/scalars, run the accelerator for `batches` batches on one context, compare each batch with the CPU
-// oracle (here: oracle/liboracle.so standing in for arkworks' VariableBaseMSM).  Built and run by tests/test_harness_cpp.py.
+// oracle (here: oracle/liboracle.so standing in for arkworks' VariableBaseMSM).  Built and run by tests/test_harness_cpp.py,
+// once per curve: the reference selects the curve at compile time with a cargo feature that becomes -DFEATURE_BLS12_377 /
+// -DFEATURE_BLS12_381 (P1A 6block/build.rs:9,82), and so does this file (it then links libmi355msm_zprize_381.so).
 #include <cstdio>
 #include <cstring>
 #include <dlfcn.h>
@@ -13,6 +15,14 @@
 #include "mi355_msm_shims.h"
 
 typedef int (*oracle_msm_t)(int, const void*, size_t, const void*, size_t, void*, int);
+
+#if defined(FEATURE_BLS12_381)
+static const int CURVE = MI355_BLS12_381_G1;
+static const uint64_t R_TOP = 0x73eda753299d7d48ull;   // top limb of the BLS12-381 group order (ARKC bls12_381/src/fields/fr.rs:4)
+#else
+static const int CURVE = MI355_BLS12_377_G1;
+static const uint64_t R_TOP = 0x12ab655e9a2ca556ull;   // ARKC bls12_377/src/fields/fr.rs:24
+#endif
 
 int main(int argc, char** argv) {
   if (argc < 3) {
@@ -29,18 +39,18 @@ int main(int argc, char** argv) {
   const size_t batches = argc > 3 ? atoi(argv[3]) : 4;
 
   std::vector<mi355::G1Affine> points(npoints);
-  mi355::check(mi355_msm_generate_points(MI355_BLS12_377_G1, 7, npoints < 2048 ? npoints : 2048, npoints, points.data(),
+  mi355::check(mi355_msm_generate_points(CURVE, 7, npoints < 2048 ? npoints : 2048, npoints, points.data(),
                                          sizeof(mi355::G1Affine)));
   points[3].infinity = 1;  // the baseline harness plants a point at infinity (P1A 6block/src/util.rs:26)
   std::mt19937_64 rng(12345);
   std::vector<mi355::BigInteger256> scalars(npoints * batches);
   for (auto& s : scalars) {
     for (int i = 0; i < 4; i++) s.limbs[i] = rng();
-    s.limbs[3] %= 0x12ab655e9a2ca556ull;  // below r
+    s.limbs[3] %= R_TOP;  // below r
   }
 
   // (1) the Rust-API mirror
-  mi355::MultiScalarMultContext ctx = mi355::multi_scalar_mult_init(points);
+  mi355::MultiScalarMultContext ctx = mi355::multi_scalar_mult_init(points, CURVE);
   std::vector<mi355::G1Projective> got = mi355::multi_scalar_mult(ctx, points, scalars);
   if (got.size() != batches) return 1;
 
@@ -53,7 +63,7 @@ int main(int argc, char** argv) {
   int bad = 0;
   for (size_t b = 0; b < batches; b++) {
     mi355::G1Projective exp;
-    if (oracle_msm(0, points.data(), sizeof(mi355::G1Affine), scalars.data() + b * npoints, npoints, &exp, 0) != 0) return 2;
+    if (oracle_msm(CURVE, points.data(), sizeof(mi355::G1Affine), scalars.data() + b * npoints, npoints, &exp, 0) != 0) return 2;
     if (memcmp(&exp, &got[b], sizeof exp) != 0 || memcmp(&exp, &got2[b], sizeof exp) != 0) {
       fprintf(stderr, "batch %zu differs from the CPU oracle\n", b);
       bad++;
@@ -61,9 +71,9 @@ int main(int argc, char** argv) {
   }
   // (3) stateless msm() chops to the shorter input
   std::vector<mi355::BigInteger256> few(scalars.begin(), scalars.begin() + 10);
-  mi355::G1Projective one = mi355::msm(points, few), exp1;
-  oracle_msm(0, points.data(), sizeof(mi355::G1Affine), few.data(), 10, &exp1, 0);
+  mi355::G1Projective one = mi355::msm(points, few, CURVE), exp1;
+  oracle_msm(CURVE, points.data(), sizeof(mi355::G1Affine), few.data(), 10, &exp1, 0);
   if (memcmp(&one, &exp1, sizeof one) != 0) bad++;
-  printf("msm_correctness npoints=2^%s batches=%zu: %s\n", argv[2], batches, bad ? "FAILED" : "ok");
+  printf("msm_correctness curve=%d npoints=2^%s batches=%zu: %s\n", CURVE, argv[2], batches, bad ? "FAILED" : "ok");
   return bad ? 1 : 0;
 }

@@ -74,17 +74,20 @@ def test_fold_is_host_side_group_addition(ea, curve):
     assert ea.fold_partials([raw], curve.name) == enc(pts[1])
 
 
-@pytest.mark.parametrize("curve", [m.BLS12_377_G1, m.BLS12_381_G1])
+@pytest.mark.parametrize("curve", [m.BLS12_377_G1, m.BLS12_381_G1, m.BLS12_377_G2, m.BLS12_381_G2], ids=lambda c: c.name)
 def test_generate_points(ea, curve):
-    """The synthetic generator mirrors the reference harness: distinct subgroup points, replicated by doubling."""
+    """The synthetic generator mirrors the reference harness: distinct subgroup points, replicated by doubling.  On-curve
+    (with the reference's b / b') and order r also pin the generator constants the engine starts from (field_consts.inc)."""
     arr = ea.generate_points(64, distinct=16, seed=5, curve=curve.name)
-    assert arr.shape == (64, 104)
+    stride, cb = curve.affine_stride, curve.coord_bytes
+    assert arr.shape == (64, stride)
     pts = [curve.decode_affine(arr[i].tobytes()) for i in range(64)]
     assert all(curve.on_curve(P) and P is not None for P in pts[:16])
-    assert len({P for P in pts[:16]}) == 16
+    key = (lambda P: P) if curve.ext == 1 else (lambda P: (P[0].c0, P[0].c1, P[1].c0, P[1].c1))
+    assert len({key(P) for P in pts[:16]}) == 16
     assert all(curve.mul(curve.r, P) is None for P in pts[:3])
     assert pts[16:32] == pts[:16] and pts[32:] == pts[:32]
-    assert (arr[:, 96:] == 0).all()
+    assert (arr[:, 2 * cb:] == 0).all()
 
 
 def test_python_mirror_argument_checks(ea):
@@ -101,7 +104,7 @@ def test_python_mirror_argument_checks(ea):
 def test_execution_plan_is_sane_and_terminates(ea):
     """mi355_msm_plan (host arithmetic): for every size class and every tuning knob the fragment merge shrinks to one lane,
     windows cover 256-bit scalars plus the signed-digit carry, and sort entries stay below 2^32."""
-    for curve in ("bls12_377_g1", "bls12_381_g1", "bls12_377_g2"):
+    for curve in ("bls12_377_g1", "bls12_381_g1", "bls12_377_g2", "bls12_381_g2"):
         for npow in (0, 1, 5, 10, 16, 20, 24, 26):
             for pre in (False, True):
                 p = ea.plan(1 << npow, curve, precompute=pre)

@@ -22,11 +22,12 @@ def test_field_ops_host(host_libs, cid):
     g.test_weak_reduce_and_bfi_step(host_libs, cid)
 
 
-def test_fp2_ops_host(host_libs):
-    g.test_fp2_products_in_every_operand_class(host_libs)
+@pytest.mark.parametrize("cid", [2, 3])
+def test_fp2_ops_host(host_libs, cid):
+    g.test_fp2_products_in_every_operand_class(host_libs, cid)
 
 
-@pytest.mark.parametrize("cid", [0, 1, 2])
+@pytest.mark.parametrize("cid", [0, 1, 2, 3])
 def test_xyzz_ops_host(host_libs, cid):
     g.test_xyzz_additions_match_the_affine_model(host_libs, cid)
 
@@ -40,7 +41,7 @@ def test_device_library_exports_and_shapes(built):
     dev = ctypes.CDLL(os.path.join(ROOT, "2022-entries_amd", "libmsm_devtest.so"))
     host = g.load_libs(False)[1]
     assert hasattr(dev, "msm_devtest_run")
-    for cid in (0, 1, 2):
+    for cid in (0, 1, 2, 3):
         for name, op in g.OPS.items():
             di, do, hi, ho = (ctypes.c_int() for _ in range(4))
             rd = dev.msm_devtest_shape(cid, op, ctypes.byref(di), ctypes.byref(do))

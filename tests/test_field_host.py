@@ -137,20 +137,20 @@ def test_weak_reduce_and_fp2_field(ht):
                 a, k = c.p - 1, 28
             assert ht.ht_fe_weak_reduce(cid, a.to_bytes(48, "little"), k, out) == 0   # also asserts result < 3p
             assert int.from_bytes(out.raw, "little") == (k * a) % c.p
-    c = m.BLS12_377_G2
-    out = ctypes.create_string_buffer(96)
-    for _ in range(200):
-        a = m.Fp2(rng.randrange(c.p), rng.randrange(c.p), c.p, c.nonresidue % c.p)
-        b = m.Fp2(rng.randrange(c.p), rng.randrange(c.p), c.p, c.nonresidue % c.p)
-        ht.ht_el_mul(2, _fp2_enc(c, a), _fp2_enc(c, b), out)
-        assert _fp2_dec(c, out.raw) == a * b
-        ht.ht_el_inv(2, _fp2_enc(c, a), out)
-        assert _fp2_dec(c, out.raw) == a.inv()
+    for cid, c in ((2, m.BLS12_377_G2), (3, m.BLS12_381_G2)):
+        out = ctypes.create_string_buffer(96)
+        for _ in range(200):
+            a = m.Fp2(rng.randrange(c.p), rng.randrange(c.p), c.p, c.nonresidue % c.p)
+            b = m.Fp2(rng.randrange(c.p), rng.randrange(c.p), c.p, c.nonresidue % c.p)
+            ht.ht_el_mul(cid, _fp2_enc(c, a), _fp2_enc(c, b), out)
+            assert _fp2_dec(c, out.raw) == a * b
+            ht.ht_el_inv(cid, _fp2_enc(c, a), out)
+            assert _fp2_dec(c, out.raw) == a.inv()
     assert ht.ht_check_failures() == 0, ht.ht_first_failure()
 
 
-def test_g2_group_law(ht):
-    c = m.BLS12_377_G2
+@pytest.mark.parametrize("cid,c", [(2, m.BLS12_377_G2), (3, m.BLS12_381_G2)], ids=["bls12_377_g2", "bls12_381_g2"])
+def test_g2_group_law(ht, cid, c):
     rng = random.Random(12)
     pts = m.random_points(c, 10, rng)
     out = ctypes.create_string_buffer(288)
@@ -159,14 +159,14 @@ def test_g2_group_law(ht):
     exp = None
     for P, ng in zip(seq, negs):
         exp = c.add(exp, c.neg(P) if ng else P)
-    ht.ht_madd_chain(2, c.encode_affine_array(seq), 200, bytes(negs), len(seq), out)
+    ht.ht_madd_chain(cid, c.encode_affine_array(seq), 200, bytes(negs), len(seq), out)
     assert out.raw == c.encode_projective_normalized(exp)
-    ht.ht_add_chains(2, c.encode_affine_array([pts[0], pts[1], pts[0], pts[1]]), 200, 2, 2, out)
+    ht.ht_add_chains(cid, c.encode_affine_array([pts[0], pts[1], pts[0], pts[1]]), 200, 2, 2, out)
     assert out.raw == c.encode_projective_normalized(c.mul(2, c.add(pts[0], pts[1])))
-    ht.ht_add_chains(2, c.encode_affine_array([pts[0], c.neg(pts[0])]), 200, 1, 1, out)
+    ht.ht_add_chains(cid, c.encode_affine_array([pts[0], c.neg(pts[0])]), 200, 1, 1, out)
     assert out.raw == c.encode_projective_normalized(None)
     sc = m.random_scalars(c, 6, rng)
     sc[1], sc[2] = 0, 1
-    ht.ht_msm_naive(2, c.encode_affine_array(pts[:6]), 200, m.encode_scalars(sc), 6, out)
+    ht.ht_msm_naive(cid, c.encode_affine_array(pts[:6]), 200, m.encode_scalars(sc), 6, out)
     assert out.raw == c.encode_projective_normalized(c.msm_naive(pts[:6], sc))
     assert ht.ht_check_failures() == 0, ht.ht_first_failure()

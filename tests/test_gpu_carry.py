@@ -14,9 +14,9 @@ from conftest import oracle_msm_np
 
 pytestmark = pytest.mark.gpu
 
-R_TOP = {0: 0x12ab655e9a2ca556, 1: 0x73eda753299d7d48, 2: 0x12ab655e9a2ca556}
-NAMES = {0: "bls12_377_g1", 1: "bls12_381_g1", 2: "bls12_377_g2"}
-STRIDE = {0: 104, 1: 104, 2: 200}
+R_TOP = {0: 0x12ab655e9a2ca556, 1: 0x73eda753299d7d48, 2: 0x12ab655e9a2ca556, 3: 0x73eda753299d7d48}
+NAMES = {0: "bls12_377_g1", 1: "bls12_381_g1", 2: "bls12_377_g2", 3: "bls12_381_g2"}
+STRIDE = {0: 104, 1: 104, 2: 200, 3: 200}
 
 
 def _scalars(cid, n, seed):
@@ -27,14 +27,14 @@ def _scalars(cid, n, seed):
 
 
 def _oracle(oracle, cid, bases, sc, n):
-    out = np.zeros(288 if cid == 2 else 144, dtype=np.uint8)
+    out = np.zeros(288 if cid >= 2 else 144, dtype=np.uint8)
     assert oracle.oracle_msm(cid, bases.ctypes.data, STRIDE[cid], np.ascontiguousarray(sc).ctypes.data, n, out.ctypes.data, 0) == 0
     return out.tobytes()
 
 
-@pytest.mark.parametrize("cid", [0, 1, 2])
+@pytest.mark.parametrize("cid", [0, 1, 2, 3])
 def test_chunked_batches_carry_their_buckets(ea, oracle, cid):
-    n = 20000 if cid != 2 else 6000
+    n = 20000 if cid < 2 else 6000
     bases = ea.generate_points(n, distinct=211, seed=13 + cid, curve=NAMES[cid])
     sc = _scalars(cid, 2 * n, 3)
     sc[7] = 0

@@ -30,7 +30,7 @@ R392 = 1 << (NL * LB)
 OPS = dict(FE_MUL=0, FE_SQR=1, FE_MUL2=2, NOT_AND_LMASK=3, EL_MUL=4, EL_SQR=5, EL_MUL_C=6, EL_MUL_C_BIG=7, EL_SQR_C=8,
            EL_MUL_SUB_C=9, MADD_COMMON=10, MADD=11, ADD=12, DBL=13, TE_MADD=14, TE_MADD_SWAPPED=15, TE_ADD=16, TE_DBL=17,
            ADD_QUAD=18, TE_ADD_QUAD=19, FE_WEAK_REDUCE=20)
-CURVES = {0: m.BLS12_377_G1, 1: m.BLS12_381_G1, 2: m.BLS12_377_G2}
+CURVES = {0: m.BLS12_377_G1, 1: m.BLS12_381_G1, 2: m.BLS12_377_G2, 3: m.BLS12_381_G2}
 
 
 # ---- limb helpers ---------------------------------------------------------------------------------------------------
@@ -221,10 +221,11 @@ def fp2_val(c, rec):
     return c.F((value_of(rec[:NL]), value_of(rec[NL:])))
 
 
-def test_fp2_products_in_every_operand_class(libs):
-    c = CURVES[2]
+@pytest.mark.parametrize("cid", [2, 3])
+def test_fp2_products_in_every_operand_class(libs, cid):
+    c = CURVES[cid]
     p = c.p
-    rng = random.Random(22)
+    rng = random.Random(20 + cid)
     n = 1 << 14
     rinv = pow(R392, -1, p)
 
@@ -246,23 +247,23 @@ def test_fp2_products_in_every_operand_class(libs):
 
     # E::mul: any lazy operands (limbs < 2^30 after the formulas' additions; values <= 18p)
     a, b = pairs(lambda: fe_classes(p, rng, n, 30, 18), lambda: fe_classes(p, rng, n, 30, 18))
-    out, _ = run_both(libs, 2, "EL_MUL", arr([x + y for x, y in zip(a, b)]))
+    out, _ = run_both(libs, cid, "EL_MUL", arr([x + y for x, y in zip(a, b)]))
     check("EL_MUL", a, b, out)
-    out, _ = run_both(libs, 2, "EL_SQR", arr(a))
+    out, _ = run_both(libs, cid, "EL_SQR", arr(a))
     check("EL_SQR", a, None, out)
     # mul_c<false>: a carried (<= 18p), b class M;  mul_c<true>: both carried, b <= 18p;  sqr_c: a carried
     a, b = pairs(lambda: carried(p, rng, n, 18), lambda: class_m(p, rng, n))
-    out, _ = run_both(libs, 2, "EL_MUL_C", arr([x + y for x, y in zip(a, b)]))
+    out, _ = run_both(libs, cid, "EL_MUL_C", arr([x + y for x, y in zip(a, b)]))
     check("EL_MUL_C", a, b, out)
     a, b = pairs(lambda: carried(p, rng, n, 18), lambda: carried(p, rng, n, 18))
-    out, _ = run_both(libs, 2, "EL_MUL_C_BIG", arr([x + y for x, y in zip(a, b)]))
+    out, _ = run_both(libs, cid, "EL_MUL_C_BIG", arr([x + y for x, y in zip(a, b)]))
     check("EL_MUL_C_BIG", a, b, out)
-    out, _ = run_both(libs, 2, "EL_SQR_C", arr(a))
+    out, _ = run_both(libs, cid, "EL_SQR_C", arr(a))
     check("EL_SQR_C", a, None, out)
     # mul_sub_c: a*b - c*d;  a, b, c carried (b <= 18p), d class M
     a, b = pairs(lambda: carried(p, rng, n, 18), lambda: carried(p, rng, n, 18))
     cc, d = pairs(lambda: carried(p, rng, n, 18), lambda: class_m(p, rng, n))
-    out, _ = run_both(libs, 2, "EL_MUL_SUB_C", arr([w + x + y + z for w, x, y, z in zip(a, b, cc, d)]))
+    out, _ = run_both(libs, cid, "EL_MUL_SUB_C", arr([w + x + y + z for w, x, y, z in zip(a, b, cc, d)]))
     for i in list(range(8)) + [rng.randrange(n) for _ in range(1000)]:
         exp = (fp2_val(c, a[i]) * fp2_val(c, b[i]) - fp2_val(c, cc[i]) * fp2_val(c, d[i])) * rinv
         assert fp2_val(c, out[i]) == exp, i
@@ -325,7 +326,7 @@ def point_cases(c, rng, n):
     return cases
 
 
-@pytest.mark.parametrize("cid", [0, 1, 2])
+@pytest.mark.parametrize("cid", [0, 1, 2, 3])
 def test_xyzz_additions_match_the_affine_model(libs, cid):
     c = CURVES[cid]
     rng = random.Random(300 + cid)

@@ -43,13 +43,72 @@ def test_native_library_is_the_one_running(ea, torch_cuda):
 
 
 def test_golden_vectors(ea, golden, torch_cuda):
-    assert {c["curve"] for c in golden} == {"bls12_377_g1", "bls12_381_g1", "bls12_377_g2"}
+    assert {c["curve"] for c in golden} == {"bls12_377_g1", "bls12_381_g1", "bls12_377_g2", "bls12_381_g2"}
     for case in golden:
         bases, scalars = bytes.fromhex(case["bases"]), bytes.fromhex(case["scalars"])
         ctx = ea.multi_scalar_mult_init(bases, case["curve"])
         got = ea.multi_scalar_mult(ctx, bases, scalars)[0]
         ctx.close()
         assert got.hex() == case["expected"], f'{case["curve"]}/{case["name"]}'
+
+
+def test_golden_vectors_large(ea, torch_cuda):
+    """tests/golden/msm_vectors_large.json: 2^10 and 2^12 pairs on all four curves (cross-checked against every reference build
+    at generation, tools/gen_golden.py), through the context path, the stateless call, and -- so that a committed fixture
+    crosses a chunk boundary -- with max_chunk forcing three chunks over carried buckets."""
+    import json
+
+    from conftest import ROOT
+    from test_oracle import _expand_large
+
+    cases = json.load(open(os.path.join(ROOT, "tests", "golden", "msm_vectors_large.json")))["cases"]
+    assert len(cases) == 8
+    for case in cases:
+        bases, scalars = _expand_large(case)
+        ctx = ea.multi_scalar_mult_init(bases, case["curve"])
+        assert ea.multi_scalar_mult(ctx, bases, scalars)[0].hex() == case["expected"], (case["curve"], case["n"])
+        ctx.set_option("max_chunk", case["n"] // 3 + 1)
+        assert ctx.run(scalars)[0].hex() == case["expected"], (case["curve"], case["n"], "three chunks")
+        ctx.close()
+        assert ea.msm(bases, scalars, case["curve"]).hex() == case["expected"], (case["curve"], case["n"], "stateless")
+
+
+@pytest.mark.parametrize("group,name", [("g1", "bls12_381_g1"), ("g2", "bls12_381_g2")])
+def test_rfc9380_vectors_held_by_the_reference(ea, torch_cuda, group, name):
+    """The reference-held BLS12-381 G1 / G2 known answers (tests/golden/h2c_kat_bls12_381.json, from the RFC 9380 vectors in
+    ARK ec/src/hashing/tests/testdata): P = h_eff (Q0 + Q1) as an MSM through the HIP path; inputs and output are literals of
+    the reference, and Q0, Q1 lie OUTSIDE the order-r subgroup."""
+    import json
+
+    from conftest import ROOT
+    from test_oracle import _h2c_point
+
+    kat = json.load(open(os.path.join(ROOT, "tests", "golden", "h2c_kat_bls12_381.json")))
+    c = m.CURVES[name]
+    chunks = [int(h, 16) for h in kat[group]["h_eff_chunks"]]
+    shift = kat["chunk_bits"]
+    all_pts, all_sc, total = [], [], None
+    for v in kat[group]["vectors"]:
+        q0, q1, P = (_h2c_point(c, v[k]) for k in ("Q0", "Q1", "P"))
+        pts, sc = [], []
+        for j, h in enumerate(chunks):
+            pts += [c.mul(1 << (shift * j), q0), c.mul(1 << (shift * j), q1)]
+            sc += [h, h]
+        assert ea.msm(c.encode_affine_array(pts), m.encode_scalars(sc), name) == c.encode_projective_normalized(P), v["msg"]
+        all_pts += pts
+        all_sc += sc
+        total = c.add(total, P)
+    assert ea.msm(c.encode_affine_array(all_pts), m.encode_scalars(all_sc), name) == c.encode_projective_normalized(total)
+    # every scalar split into eight non-negative integer shares (exact over the integers: Q0, Q1 are not in the r-torsion, so
+    # shares may not be reduced modulo r): 8x the pairs, the same literal total
+    rng = random.Random(9380)
+    shares_pts, shares_sc = [], []
+    for P, k in zip(all_pts, all_sc):
+        cut = sorted(rng.randrange(k + 1) for _ in range(7))
+        parts = [b - a for a, b in zip([0] + cut, cut + [k])]     # eight non-negative integers summing to k exactly
+        shares_pts += [P] * 8
+        shares_sc += parts
+    assert ea.msm(c.encode_affine_array(shares_pts), m.encode_scalars(shares_sc), name) == c.encode_projective_normalized(total)
 
 
 @pytest.mark.parametrize("cid,curve", CURVES)
@@ -269,31 +328,37 @@ def test_randomized_sizes_and_knobs(ea, oracle, torch_cuda):
 
 # ---- G2 (BASELINE.json configs[4]): Fq2 coordinates through the same kernels ------------------------------------
 
-def _oracle_g2(oracle, bases_np, scalars_np, n):
+def _oracle_g2(oracle, bases_np, scalars_np, n, cid=2):
     out = ctypes.create_string_buffer(288)
-    assert oracle.oracle_msm(2, bases_np.ctypes.data, 200, scalars_np.ctypes.data, n, out, 0) == 0
+    assert oracle.oracle_msm(cid, bases_np.ctypes.data, 200, scalars_np.ctypes.data, n, out, 0) == 0
     return out.raw
 
 
+# (engine / oracle curve id, model, which r bounds the synthetic scalars)
+G2_CURVES = [pytest.param(2, m.BLS12_377_G2, 0, id="bls12_377_g2"), pytest.param(3, m.BLS12_381_G2, 1, id="bls12_381_g2")]
+
+
+@pytest.mark.parametrize("cid,c,rid", G2_CURVES)
 @pytest.mark.parametrize("npow", [8, 12, 16])
-def test_g2_random_vs_oracle(ea, oracle, torch_cuda, npow):
+def test_g2_random_vs_oracle(ea, oracle, torch_cuda, npow, cid, c, rid):
     n = 1 << npow
-    bases = ea.generate_points(n, distinct=min(n, 256), seed=npow, curve="bls12_377_g2")
+    bases = ea.generate_points(n, distinct=min(n, 256), seed=npow, curve=c.name)
     assert bases.shape == (n, 200)
-    scalars = rand_scalars_np(0, 2 * n, seed=500 + npow)
-    ctx = ea.multi_scalar_mult_init(torch_cuda.from_numpy(bases).cuda(), "bls12_377_g2")
+    scalars = rand_scalars_np(rid, 2 * n, seed=500 + npow)
+    ctx = ea.multi_scalar_mult_init(torch_cuda.from_numpy(bases).cuda(), c.name)
     got = ea.multi_scalar_mult(ctx, None, torch_cuda.from_numpy(scalars).cuda())
     assert len(got) == 2 and len(got[0]) == 288
     for b in range(2):
-        assert got[b] == _oracle_g2(oracle, bases, np.ascontiguousarray(scalars[b * n:(b + 1) * n]), n), (npow, b)
+        assert got[b] == _oracle_g2(oracle, bases, np.ascontiguousarray(scalars[b * n:(b + 1) * n]), n, cid), (npow, b)
     ctx.close()
 
 
-def test_g2_reference_generator_has_order_r_on_the_gpu(ea, golden_constants, torch_cuda):
-    """The reference's G2 generator literal (tests/golden/constants.json, from ARKC bls12_377/src/curves/g2.rs:61-78) through the
-    HIP path: r * G2 = O, (r - 1) * G2 = -G2, and 2^15 copies of G2 with scalars summing to r also vanish."""
-    c = m.BLS12_377_G2
-    k = golden_constants["bls12_377_g2"]
+@pytest.mark.parametrize("cid,c,rid", G2_CURVES)
+def test_g2_reference_generator_has_order_r_on_the_gpu(ea, golden_constants, torch_cuda, cid, c, rid):
+    """The reference's G2 generator literals (tests/golden/constants.json, from ARKC bls12_377/src/curves/g2.rs:61-78 and
+    bls12_381/src/curves/g2.rs:74-91) through the HIP path: r * G2 = O, (r - 1) * G2 = -G2, and 2^15 copies of G2 with scalars
+    summing to r also vanish."""
+    k = golden_constants[c.name]
     G = c.generator()
     assert (G[0].c0, G[0].c1, G[1].c0, G[1].c1) == tuple(int(k[n]) for n in ("GX0", "GX1", "GY0", "GY1")) and c.on_curve(G)
     base = c.encode_affine_array([G])
@@ -306,8 +371,8 @@ def test_g2_reference_generator_has_order_r_on_the_gpu(ea, golden_constants, tor
     assert ea.msm(base * n, m.encode_scalars(sc), c.name) == c.encode_projective_normalized(None)
 
 
-def test_g2_edge_cases_and_stateless(ea, oracle, torch_cuda):
-    c = m.BLS12_377_G2
+@pytest.mark.parametrize("cid,c,rid", G2_CURVES)
+def test_g2_edge_cases_and_stateless(ea, oracle, torch_cuda, cid, c, rid):
     rng = random.Random(77)
     for n in (0, 1, 2, 31, 33, 300):
         pts = m.random_points(c, n, rng, max(1, n // 4)) if n else []
@@ -321,25 +386,26 @@ def test_g2_edge_cases_and_stateless(ea, oracle, torch_cuda):
     n = 2000
     bases = ea.generate_points(n, distinct=16, seed=2, curve=c.name)
     ctx = ea.multi_scalar_mult_init(bases, c.name)
-    same = np.tile(rand_scalars_np(0, 1, 3), (n, 1))
-    assert ea.multi_scalar_mult(ctx, bases, same)[0] == _oracle_g2(oracle, bases, np.ascontiguousarray(same), n)
-    sc = rand_scalars_np(0, n, 4)
+    same = np.tile(rand_scalars_np(rid, 1, 3), (n, 1))
+    assert ea.multi_scalar_mult(ctx, bases, same)[0] == _oracle_g2(oracle, bases, np.ascontiguousarray(same), n, cid)
+    sc = rand_scalars_np(rid, n, 4)
     whole = ea.multi_scalar_mult(ctx, bases, sc)[0]
     lo = ctx.run(np.ascontiguousarray(sc[:n // 2]), npoints=n // 2)[0]
     ctx2 = ea.multi_scalar_mult_init(np.ascontiguousarray(bases[n // 2:]), c.name)
     hi = ctx2.run(np.ascontiguousarray(sc[n // 2:]))[0]
-    assert ea.fold_partials([lo, hi], c.name) == whole == _oracle_g2(oracle, bases, sc, n)
+    assert ea.fold_partials([lo, hi], c.name) == whole == _oracle_g2(oracle, bases, sc, n, cid)
     ctx.close()
     ctx2.close()
 
 
+@pytest.mark.parametrize("cid,c,rid", G2_CURVES)
 @pytest.mark.parametrize("npow", [20, 24])
-def test_g2_full_size_properties(ea, oracle, torch_cuda, npow):
-    """BLS12-377 G2 at 2^24 pairs (BASELINE.json configs[4]): linearity + prefix parity (the CPU oracle needs minutes at this size)."""
+def test_g2_full_size_properties(ea, oracle, torch_cuda, npow, cid, c, rid):
+    """G2 at 2^24 pairs (BASELINE.json configs[4] is the BLS12-377 one): linearity + prefix parity (the CPU oracle needs minutes at this size)."""
     torch = torch_cuda
     n = 1 << npow
     distinct = 1 << 12
-    tile = ea.generate_points(distinct, distinct=distinct, seed=6, curve="bls12_377_g2")
+    tile = ea.generate_points(distinct, distinct=distinct, seed=6, curve=c.name)
     bases = torch.from_numpy(tile).cuda().repeat(n // distinct, 1).contiguous()
     g = torch.Generator(device="cuda")
     g.manual_seed(npow)
@@ -351,17 +417,17 @@ def test_g2_full_size_properties(ea, oracle, torch_cuda, npow):
     as_bytes = lambda t: t.view(torch.uint8).reshape(-1, 32)
     ksum = k1.clone()
     ksum[:, 3] += k2[:, 3]
-    ctx = ea.MultiScalarMultContext("bls12_377_g2")
+    ctx = ea.MultiScalarMultContext(c.name)
     ctx.set_bases(bases)
     r1 = ctx.run(as_bytes(k1))[0]
     r2 = ctx.run(as_bytes(k2))[0]
     r12 = ctx.run(as_bytes(ksum))[0]
-    assert ea.fold_partials([r1, r2], "bls12_377_g2") == r12
+    assert ea.fold_partials([r1, r2], c.name) == r12
     sample = 1 << 13
     sc = as_bytes(k1[:sample].contiguous()).cpu().numpy()
     assert ctx.run(as_bytes(k1[:sample].contiguous()), npoints=sample)[0] == _oracle_g2(
-        oracle, np.ascontiguousarray(np.tile(tile, (sample // distinct, 1))), sc, sample)
-    print("G2 2^%d timings: %s" % (npow, ctx.last_timings()))
+        oracle, np.ascontiguousarray(np.tile(tile, (sample // distinct, 1))), sc, sample, cid)
+    print("%s 2^%d timings: %s" % (c.name, npow, ctx.last_timings()))
     ctx.close()
 
 

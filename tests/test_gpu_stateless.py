@@ -42,7 +42,7 @@ class _Env:
                 os.environ[k] = v
 
 
-@pytest.mark.parametrize("curve,cid", [("bls12_377_g1", 0), ("bls12_381_g1", 1), ("bls12_377_g2", 2)])
+@pytest.mark.parametrize("curve,cid", [("bls12_377_g1", 0), ("bls12_381_g1", 1), ("bls12_377_g2", 2), ("bls12_381_g2", 3)])
 def test_stateless_matches_oracle_for_every_slicing(ea, oracle, curve, cid):
     """Slices of 2^10 / 2^12 pairs (ragged last slice, more slices than raw-record buffers, so the ring of three wraps),
     1 and 5 staging threads, and the automatic choice."""

@@ -105,7 +105,7 @@ def test_hashmap_pippenger_fr_montgomery_scalars(ea, oracle):
     hp.close()
 
 
-@pytest.mark.parametrize("curve,cid", [("bls12_381_g1", 1), ("bls12_377_g2", 2)])
+@pytest.mark.parametrize("curve,cid", [("bls12_381_g1", 1), ("bls12_377_g2", 2), ("bls12_381_g2", 3)])
 def test_stream_other_curves(ea, oracle, curve, cid):
     n = 900
     bases = ea.generate_points(n, distinct=60, seed=6, curve=curve)

@@ -40,7 +40,7 @@ def _exports(lib):
 
 
 def test_crate_files_present():
-    for f in ("Cargo.toml", "build.rs", "src/lib.rs", "src/util.rs", "tests/msm.rs", "benches/msm.rs"):
+    for f in ("Cargo.toml", "build.rs", "src/lib.rs", "src/util.rs", "tests/msm.rs"):
         assert os.path.exists(os.path.join(RUST, f)), f
     toml = open(os.path.join(RUST, "Cargo.toml")).read()
     for dep in ('ark-ec = { version = "0.3.0"', 'ark-ff = "0.3.0"', 'ark-bls12-377 = { version = "0.3.0"'):

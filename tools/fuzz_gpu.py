@@ -11,14 +11,14 @@ import te_model as te
 
 lib = ctypes.CDLL(os.path.join(ROOT, "oracle", "liboracle.so"))
 lib.oracle_msm.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_int]
-CURVES = [("bls12_377_g1", 0, 0x12ab655e9a2ca556), ("bls12_381_g1", 1, 0x73eda753299d7d48), ("bls12_377_g2", 2, 0x12ab655e9a2ca556)]
+CURVES = [("bls12_377_g1", 0, 0x12ab655e9a2ca556), ("bls12_381_g1", 1, 0x73eda753299d7d48), ("bls12_377_g2", 2, 0x12ab655e9a2ca556), ("bls12_381_g2", 3, 0x73eda753299d7d48)]
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 bad = 0
 for case in range(cases):
-    name, cid, top = CURVES[rng.choice([0, 0, 1, 1, 2])]
+    name, cid, top = CURVES[rng.choice([0, 0, 0, 1, 1, 1, 2, 3])]
     n = rng.choice([1, 2, 5, 31, 32, 33, 100, 257, 1023, 1024, 3000, 8191, 8193, 9999, 40000, 70001, 200000])
-    if cid == 2:
+    if cid >= 2:
         n = min(n, 3000)
     stride = ea.affine_stride(name)
     bases = ea.generate_points(n, distinct=rng.choice([1, 3, 50, n]), seed=case, curve=name)
