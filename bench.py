@@ -31,7 +31,7 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
-BYTES_PER_PAIR = {0: 128.0, 1: 128.0, 2: 224.0}   # 32 B scalar + 96 B affine base (G2: + 192 B)
+BYTES_PER_PAIR = {0: 128.0, 1: 128.0, 2: 224.0, 3: 224.0}   # 32 B scalar + 96 B affine base (G2: + 192 B)
 R377_TOP = 0x12ab655e9a2ca556   # top 64-bit limb of the BLS12-377 scalar modulus (ARKC bls12_377/src/fields/fr.rs:24)
 R381_TOP = 0x73eda753299d7d48
 
@@ -85,7 +85,7 @@ def timed(fn, reps):
 def cpu_baseline(curve, cid, bases_np, scalars_np, sample, threads):
     """Time the oracle (arkworks-algorithm restatement) on `sample` pairs; returns (pairs/s, result bytes, seconds)."""
     lib = ctypes.CDLL(os.path.join(ROOT, "oracle", "liboracle.so"))
-    out = ctypes.create_string_buffer(288 if cid == 2 else 144)
+    out = ctypes.create_string_buffer(288 if cid >= 2 else 144)
     t0 = time.perf_counter()
     rc = lib.oracle_msm(cid, bases_np.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(bases_np.shape[1]),
                         scalars_np.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(sample), out, threads)
@@ -104,7 +104,7 @@ def main():
     ap.add_argument("--total-npow", type=int, default=-1,
                     help="log2 pairs of the WHOLE job, split evenly over the GPUs (overrides --npow); default: 28 when --gpus 8 "
                          "(BASELINE.json configs[3]), otherwise unset (2^npow per GPU); 0 = never")
-    ap.add_argument("--curve", default="bls12_377_g1", choices=["bls12_377_g1", "bls12_381_g1", "bls12_377_g2"])
+    ap.add_argument("--curve", default="bls12_377_g1", choices=["bls12_377_g1", "bls12_381_g1", "bls12_377_g2", "bls12_381_g2"])
     ap.add_argument("--cpu-sample-pow", type=int, default=26,
                     help="log2 pairs of the CPU-baseline sample (0 = skip); 26 = the whole workload once, about a minute of host time")
     ap.add_argument("--extras", type=int, default=1,
@@ -170,7 +170,7 @@ def main():
     base_tile = ea.generate_points(distinct, distinct=distinct, seed=0x5A5052495A45 + cid, curve=args.curve)
     tile = torch.from_numpy(base_tile).to(device)
     bases = tile.repeat(n // distinct, 1).contiguous()
-    scalars = uniform_scalars(n, R381_TOP if cid == 1 else R377_TOP, device, seed=1234 + rank)
+    scalars = uniform_scalars(n, R381_TOP if cid in (1, 3) else R377_TOP, device, seed=1234 + rank)
     if c_sharded:
         ndev = torch.cuda.device_count()
         if ndev < args.gpus and not args.logical_shards:
@@ -179,7 +179,7 @@ def main():
         ctx = ea.MultiScalarMultContext(args.curve, devices=devs)
         # weak scaling: 2^npow pairs PER GPU; the global problem is args.gpus times as large
         bases = bases.repeat(args.gpus, 1)
-        scalars = torch.cat([uniform_scalars(n, R381_TOP if cid == 1 else R377_TOP, device, seed=1234 + g) for g in range(args.gpus)])
+        scalars = torch.cat([uniform_scalars(n, R381_TOP if cid in (1, 3) else R377_TOP, device, seed=1234 + g) for g in range(args.gpus)])
     else:
         ctx = ea.MultiScalarMultContext(args.curve, device=local_rank)
     if args.window_bits:
@@ -291,9 +291,9 @@ def main():
         # They are NOT measured by this run (counters need their own rocprofv3 pass): `traffic_from` says where the figure was
         # measured, and it is only quoted when that pass ran on the very kernel sources this library was built from.
         traffic, traffic_raw, traffic_from, valu = None, None, None, None
-        pmc_rel = os.path.join("profiles", "r03_pmc_k_accumulate%s.json" % {0: "", 1: "_381", 2: "_g2"}[cid])
+        pmc_rel = os.path.join("profiles", "r03_pmc_k_accumulate%s.json" % {0: "", 1: "_381", 2: "_g2", 3: "_381g2"}[cid])
         pmc_path = os.path.join(ROOT, pmc_rel)
-        if (args.npow == (24 if cid == 2 else 26) and not total_npow and not args.window_bits and not args.lane_entries and not args.precompute
+        if (args.npow == (24 if cid >= 2 else 26) and not total_npow and not args.window_bits and not args.lane_entries and not args.precompute
                 and os.path.exists(pmc_path)):
             pmc = json.load(open(pmc_path))
             sha = kernel_source_sha16()
@@ -314,12 +314,12 @@ def main():
         te_path = ctx_te_path
         # v_mad_u64_u32 per mixed addition: a property of the formulas (7 multiplications of 378; 6M + 2S + one fused dual product),
         # pinned on the generated ISA by tests/test_isa.py
-        mads_per_add = {0: 2646 if te_path else 3416, 1: 3542, 2: 11584}[cid]
+        mads_per_add = {0: 2646 if te_path else 3416, 1: 3542, 2: 11584, 3: 11584}[cid]
         adds_per_launch = tm["entries"]          # one mixed addition per sorted entry (zero digits are a ~1e-6 fraction)
         mad_rate = mads_per_add * adds_per_launch / kern_s
         mad_peak = 1024 * 64 / 4.3 * 2.4e9
         out = {
-            "metric": {0: "BLS12-377 G1", 1: "BLS12-381 G1", 2: "BLS12-377 G2"}[cid] + " MSM point-scalar pairs/s",
+            "metric": {0: "BLS12-377 G1", 1: "BLS12-381 G1", 2: "BLS12-377 G2", 3: "BLS12-381 G2"}[cid] + " MSM point-scalar pairs/s",
             "value": value,
             "unit": "pairs/s",
             "n_gpus": args.gpus if c_sharded else world,
@@ -356,7 +356,7 @@ def main():
                                      "peak_is": "v_mad_u64_u32 issue limit at the nominal 2.4 GHz; the kernel runs power-limited near 1.9 GHz"},
                          "note": "integer-VALU-bound path (no MFMA): the binding resource is VALU issue at the power-limited clock (DESIGN.md section 5)"},
         }
-        if world == 1 and not c_sharded and args.extras and cid != 2:
+        if world == 1 and not c_sharded and args.extras and cid < 2:
             # SURVEY 8(d)'s PRIMARY metric is what the reference bench times: bases resident, scalars in HOST memory, 4 batches
             # (P1A combined-top-solutions/benches/msm.rs:21,27-35).  `value` above keeps the scalars in HBM (the brief's rule);
             # these are the PCIe-inclusive figures, measured in this same run.
@@ -367,7 +367,7 @@ def main():
                 ms1_page, r1 = timed(lambda: ctx.run(sc_np)[0], 3)
                 ms1_pin, r1p = timed(lambda: ctx.run(sc_pin)[0], 3)
                 extras["host_scalars"] = {"one_batch_ms": {"pageable": ms1_page, "pinned": ms1_pin}, "same_result_as_device_scalars": r1 == result and r1p == result}
-                sc4 = torch.cat([uniform_scalars(n, R381_TOP if cid == 1 else R377_TOP, device, seed=4000 + b) for b in range(4)])
+                sc4 = torch.cat([uniform_scalars(n, R381_TOP if cid in (1, 3) else R377_TOP, device, seed=4000 + b) for b in range(4)])
                 sc4_np = sc4.cpu().numpy()
                 sc4_pin = torch.from_numpy(sc4_np).pin_memory()
                 ms4_dev, r4 = timed(lambda: ctx.run(sc4), 2)
@@ -432,11 +432,12 @@ def main():
             # the second 384-bit prime (no Edwards form: XYZZ) and G2 over Fq2.  Scalars resident in HBM, as for `value`.
             ctx.close()   # hand the headline context's memory back first
             sec = {}
-            for name, cname, npow2 in (("bls12_381_g1_2^26", "bls12_381_g1", 26), ("bls12_377_g2_2^24", "bls12_377_g2", 24)):
+            for name, cname, npow2 in (("bls12_381_g1_2^26", "bls12_381_g1", 26), ("bls12_377_g2_2^24", "bls12_377_g2", 24),
+                                       ("bls12_381_g2_2^24", "bls12_381_g2", 24)):
                 try:
                     cid2, n2 = ea.CURVE_IDS[cname], 1 << npow2
                     tile2 = torch.from_numpy(ea.generate_points(distinct, distinct=distinct, seed=0x5A5052495A45 + cid2, curve=cname)).to(device)
-                    sc2 = uniform_scalars(n2, R381_TOP if cid2 == 1 else R377_TOP, device, seed=99 + cid2)
+                    sc2 = uniform_scalars(n2, R381_TOP if cid2 in (1, 3) else R377_TOP, device, seed=99 + cid2)
                     c2 = ea.MultiScalarMultContext(cname, device=local_rank)
                     c2.set_bases(tile2.repeat(n2 // distinct, 1).contiguous())
                     ms2, _ = timed(lambda: c2.run(sc2)[0], 3)
@@ -478,12 +479,12 @@ def main():
         if world == 1 and not c_sharded and args.cpu_sample_pow > 0:
             sample = min(n, 1 << args.cpu_sample_pow)
             cores = os.cpu_count() or 1
-            if cid == 2:
+            if cid >= 2:
                 sample = min(sample, 1 << 21)   # Fp2 arithmetic is ~3x slower on the CPU too
             bases_np = np.ascontiguousarray(np.tile(base_tile, (max(1, sample // distinct), 1))[:sample])
             scal_np = scalars[:sample].cpu().numpy()
             c = 3 if sample < 32 else (((sample - 1).bit_length()) * 69 // 100 + 2)
-            windows = -(-(255 if cid == 1 else 253) // c)
+            windows = -(-(255 if cid in (1, 3) else 253) // c)
             threads = min(windows, cores)
             v, cpu_res, dt = cpu_baseline(args.curve, cid, bases_np, scal_np, sample, threads)
             # same sample on the GPU: a parity spot-check next to the number (`result` is the headline run's point when the
@@ -499,7 +500,7 @@ def main():
                                    "sample": f"first 2^{sample.bit_length() - 1} pairs of the same workload, {dt:.1f} s, "
                                              f"arkworks-algorithm restatement (c={c}, one thread per window), host has {cores} cores",
                                    "gpu_matches_cpu_on_sample": gpu_res == cpu_res}
-        if world == 1 and not c_sharded and args.also_precompute and not args.precompute and cid != 2:
+        if world == 1 and not c_sharded and args.also_precompute and not args.precompute and cid < 2:
             # the reference's own convention (init untimed, tables built there): reported next to the headline, not as it
             try:
                 ctx.close()   # give the headline context's ~40 GB back before the tables (95 + 142 GB while they are converted)
