@@ -19,6 +19,8 @@ from .msm import (  # noqa: F401
     plan,
     msm,
     last_stateless,
+    trim,
+    pool_stats,
     ChunkedPippenger,
     HashMapPippenger,
 )

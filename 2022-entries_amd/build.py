@@ -40,9 +40,24 @@ def hipcc() -> str:
 ENGINE_UNITS = ["msm_engine.hip", "partition.hip", "kernels_377g1.hip", "kernels_381g1.hip", "kernels_377g2.hip", "kernels_381g2.hip", "kernels_377te.hip"]
 
 
+def _depfile_deps(dfile: str):
+    """Prerequisites listed by a make-style dependency file (hipcc -MD -MF), or None when it is missing / unreadable."""
+    try:
+        txt = open(dfile).read().replace("\\\n", " ")
+    except OSError:
+        return None
+    deps = []
+    for rule in txt.split("\n"):
+        if ":" in rule:
+            deps += [d for d in rule.split(":", 1)[1].split() if not d.startswith("/opt/") and not d.startswith("/usr/")]
+    return deps or None
+
+
 def build_engine(force: bool = False) -> str:
     """hipcc --offload-arch=gfx950: one object per translation unit (the per-curve kernel units take minutes each --
-    every field multiply is fully unrolled -- so they are compiled in parallel), then one link into libmi355msm.so."""
+    every field multiply is fully unrolled -- so they are compiled in parallel), then one link into libmi355msm.so.
+    A unit is rebuilt when one of the files IT includes changed (dependency files written by hipcc -MD): a change to the host
+    orchestration does not recompile the kernel units."""
     out = os.path.join(PKG, "libmi355msm.so")
     headers = [f for f in glob.glob(os.path.join(CSRC, "*")) if not f.endswith(".hip") and os.path.isfile(f)]
     abi_headers = glob.glob(os.path.join(ROOT, "include", "*.h"))   # only the engine unit includes the C ABI header
@@ -53,9 +68,13 @@ def build_engine(force: bool = False) -> str:
     for unit in ENGINE_UNITS:
         src = os.path.join(CSRC, unit)
         obj = os.path.join(objdir, unit.replace(".hip", ".o"))
+        dfile = obj + ".d"
         objs.append(obj)
-        if force or _newer(obj, headers + [src] + (abi_headers if unit == "msm_engine.hip" else [])):
-            cmd = [cc, "--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-c", src, "-o", obj]
+        deps = _depfile_deps(dfile)
+        if deps is None or not all(os.path.exists(d) for d in deps):
+            deps = headers + [src] + (abi_headers if unit == "msm_engine.hip" else [])
+        if force or _newer(obj, deps):
+            cmd = [cc, "--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-MD", "-MF", dfile, "-c", src, "-o", obj]
             print("+", " ".join(cmd), flush=True)
             jobs.append((unit, subprocess.Popen(cmd)))
     failed = [unit for unit, pr in jobs if pr.wait() != 0]

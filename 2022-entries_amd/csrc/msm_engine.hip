@@ -107,6 +107,10 @@ RustError guarded_dev(Fn&& fn) {
   return guarded(fn);
 }
 
+// Device memory this library holds WITHOUT a caller knowing -- the cached contexts of the stateless call (msm_stateless.hpp) -- is
+// given back before any allocation is allowed to fail: returns true when something was freed.
+bool reclaim_idle_device_memory();
+
 struct DevBuf {
   void* p = nullptr;
   size_t bytes = 0;
@@ -114,6 +118,10 @@ struct DevBuf {
     if (need <= bytes) return;
     release();
     hipError_t e = hipMalloc(&p, need);
+    if (e == hipErrorOutOfMemory) {
+      (void)hipGetLastError();
+      if (reclaim_idle_device_memory()) e = hipMalloc(&p, need);
+    }
     if (e != hipSuccess) {
       p = nullptr;
       (void)hipGetLastError();   // clear the sticky per-thread error so that a retry with smaller buffers starts clean
@@ -431,6 +439,16 @@ void release_work_buffers(mi355_msm_ctx* ctx, bool keep_carry = false) {
   DevBuf* const* wb = work_buffers(ctx, nb);
   for (size_t i = 0; i < nb; i++)
     if (!(keep_carry && wb[i] == &ctx->carry_buckets)) wb[i]->release();
+}
+
+// Everything the context holds in device memory (the stateless pool's size bound, msm_stateless.hpp).
+size_t ctx_device_bytes(mi355_msm_ctx* ctx) {
+  size_t nb = 0, total = 0;
+  DevBuf* const* wb = work_buffers(ctx, nb);
+  for (size_t i = 0; i < nb; i++) total += wb[i]->bytes;
+  total += ctx->bases.bytes + ctx->inf.bytes + ctx->scalars.bytes;
+  for (const DevBuf& r : ctx->stateless_raw) total += r.bytes;
+  return total;
 }
 
 // Run `fn.template operator()<Curve>()` for the curve id.
@@ -1521,20 +1539,30 @@ RustError mi355_msm_last_stateless(double* out, size_t count) {
 RustError mi355_msm_trim(void) {
   return guarded_dev([&] {
     std::vector<StageRing*> rings;
-    std::vector<mi355_msm_ctx*> idle;
     {
       std::lock_guard<std::mutex> lk(g_ring_mu);
       rings.swap(g_rings_idle);
-      idle.swap(g_stateless_idle);
     }
     for (StageRing* r : rings) {
       (void)hipSetDevice(r->device);
       ring_destroy(r);
     }
-    for (mi355_msm_ctx* c : idle) {
-      RustError d = mi355_msm_destroy(c);
-      if (d.message) free(d.message);
+    (void)reclaim_idle_device_memory();
+  });
+}
+
+RustError mi355_msm_pool_stats(uint64_t* out, size_t count) {
+  return guarded([&] {
+    if (!out) bad_arg("null output");
+    uint64_t v[4] = {0, 0, 0, 0};
+    {
+      std::lock_guard<std::mutex> lk(g_ring_mu);
+      v[0] = g_stateless_idle.size();
+      for (mi355_msm_ctx* c : g_stateless_idle) v[1] += ctx_device_bytes(c);
+      v[2] = g_rings_idle.size();
+      v[3] = v[2] * StageRing::SLOTS * StageRing::PIECE;
     }
+    for (size_t i = 0; i < count && i < 4; i++) out[i] = v[i];
   });
 }
 

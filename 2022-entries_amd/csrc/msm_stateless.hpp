@@ -84,8 +84,17 @@ void ring_release(StageRing* r) {
 // The device side of a stateless call -- a context with its raw-record, base, scalar and work buffers (~9 GB at 2^26) -- is
 // kept between calls too: measured, a call that frees its buffers makes the NEXT call's first hipMalloc wait ~280 ms
 // (the driver releases the memory asynchronously; profiles/r03_stateless_probe.txt), and growing the work buffers from the
-// short first slice to the regular one cost 30 ms inside the pipeline.  Keyed by (curve, device); mi355_msm_trim() frees them.
+// short first slice to the regular one cost 30 ms inside the pipeline.
+//
+// What is retained, and its bounds: at most ONE idle context per (curve, device) -- a second concurrent caller's context
+// is destroyed when it comes back and finds the slot taken; a context that holds more than MI355_MSM_STATELESS_KEEP_MB of device
+// memory (default 16384: a 2^26-pair G1 call holds ~9 GB) gives its buffers back before it is parked (the next call of that size
+// pays the allocation again); any device allocation of this library that fails with out-of-memory first frees ALL idle contexts and
+// retries (DevBuf::reserve -> reclaim_idle_device_memory) before a run falls back to smaller chunks; mi355_msm_trim() frees them
+// and the pinned rings on request.  Documented in INTEGRATION.md section 4.
 std::vector<mi355_msm_ctx*> g_stateless_idle;
+
+long env_long(const char* name, long dflt, long lo, long hi);
 
 struct StatelessLease {
   mi355_msm_ctx* ctx = nullptr;
@@ -107,9 +116,23 @@ struct StatelessLease {
   ~StatelessLease() {
     if (!ctx) return;
     if (ok) {
+      const long keep_mb = env_long("MI355_MSM_STATELESS_KEEP_MB", 16384, 0, 1l << 30);
+      if (ctx_device_bytes(ctx) > ((size_t)keep_mb << 20)) {
+        release_work_buffers(ctx);
+        ctx->scalars.release();
+        ctx->bases.release();
+        ctx->inf.release();
+        for (DevBuf& r : ctx->stateless_raw) r.release();
+      }
       std::lock_guard<std::mutex> lk(g_ring_mu);
-      g_stateless_idle.push_back(ctx);
-    } else {
+      bool taken = false;
+      for (mi355_msm_ctx* c : g_stateless_idle) taken = taken || (c->curve == ctx->curve && c->device == ctx->device);
+      if (!taken) {
+        g_stateless_idle.push_back(ctx);
+        ctx = nullptr;
+      }
+    }
+    if (ctx) {   // a failed call, or the slot of this (curve, device) is taken: one idle context per key, no more
       RustError d = mi355_msm_destroy(ctx);
       if (d.message) free(d.message);
     }
@@ -117,6 +140,21 @@ struct StatelessLease {
   StatelessLease(const StatelessLease&) = delete;
   StatelessLease& operator=(const StatelessLease&) = delete;
 };
+
+bool reclaim_idle_device_memory() {
+  std::vector<mi355_msm_ctx*> idle;
+  {
+    std::lock_guard<std::mutex> lk(g_ring_mu);
+    idle.swap(g_stateless_idle);
+  }
+  if (idle.empty()) return false;
+  DeviceGuard keep;   // destroying a context of another device must not move the caller
+  for (mi355_msm_ctx* c : idle) {
+    RustError d = mi355_msm_destroy(c);
+    if (d.message) free(d.message);
+  }
+  return true;
+}
 
 // What the most recent stateless call of this thread did (mi355_msm_last_stateless).
 struct StatelessStats {

@@ -38,6 +38,20 @@
 
 namespace msm {
 
+// Workgroup barrier that orders LDS traffic ONLY.  __syncthreads() is `s_waitcnt vmcnt(0) lgkmcnt(0); s_barrier`: every barrier of
+// a scattering block then also waits for the global loads it issued ahead (the next tile) and for its global STORES to be
+// acknowledged (gfx9 counts them in vmcnt) -- the memory pipeline drains at each of the five to eight barriers of a tile step, and
+// the step costs compute + memory instead of their maximum (profiles/r04_ab_group_barrier.txt).  The kernels below exchange data
+// between threads through LDS alone (global memory is read-only input or write-only output within a launch), so waiting for the
+// LDS counter is all the barrier needs; the "memory" clobber keeps the compiler from moving accesses across it.
+__device__ __forceinline__ void lds_barrier() {
+#ifdef PART_FULL_BARRIER
+  __syncthreads();
+#else
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+}
+
 // ---- block-wide exclusive scan of one value per thread (blockDim.x a multiple of 64, <= 1024) --------------------------
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
 #pragma unroll
@@ -47,22 +61,24 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
   }
   return v;
 }
-// tmp: >= 17 words of LDS.  Returns the exclusive prefix of v; total of the block in `total`.  Ends with a barrier.
+// tmp: >= 17 words of LDS.  Returns the exclusive prefix of v; total of the block in `total`.  Ends with a barrier unless
+// TAIL_BARRIER = false: the caller then guarantees a barrier of its own before `tmp` is used again.
+template <bool TAIL_BARRIER = true>
 __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* tmp, uint32_t& total) {
   const uint32_t incl = wave_incl_scan(v);
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
   if (lane == 63) tmp[wave] = incl;
-  __syncthreads();
+  lds_barrier();
   if (wave == 0) {
     uint32_t w = lane < nw ? tmp[lane] : 0;
     const uint32_t wi = wave_incl_scan(w);
     if (lane < nw) tmp[lane] = wi - w;
     if (lane == nw - 1) tmp[16] = wi;
   }
-  __syncthreads();
+  lds_barrier();
   const uint32_t r = tmp[wave] + incl - v;
   total = tmp[16];
-  __syncthreads();
+  if (TAIL_BARRIER) lds_barrier();
   return r;
 }
 
@@ -79,13 +95,38 @@ struct ScalarDigits {
 // window of r (wave-uniform: scalar registers), the borrow in bit 1 of `carry` -- the level-1 scatter holds eight scalars per
 // thread in a 128-VGPR budget, and neither a pass over them nor a ninth register per scalar fits (both spilled).
 // FOLD = false (the default path) compiles to the plain recoding: the option costs nothing when it is off.
+//
+// The window is cut straight out of the scalar (round 4): bits [o, o + 32) with o = w c are one v_alignbit of two neighbouring
+// words, and WHICH two is wave-uniform (w and c are), so the choice is a scalar branch, not a select chain.  Before, the whole
+// 8-word scalar was shifted down by c bits after every window: 8 quarter-rate shifts per digit, half of what the level-1
+// kernels spent (profiles/r04_ab_group_digits.txt).
+template <int L>
+__device__ __forceinline__ uint32_t scalar_bits_at(const uint32_t (&s)[8], uint32_t sh) {
+  if constexpr (L >= 8) {
+    return 0;
+  } else {
+    const uint32_t hi = L < 7 ? s[L < 7 ? L + 1 : 7] : 0u;
+    return __builtin_amdgcn_alignbit(hi, s[L], sh);
+  }
+}
+__device__ __forceinline__ uint32_t scalar_window(const uint32_t (&s)[8], uint32_t o) {
+  const uint32_t sh = o & 31;
+  switch (o >> 5) {   // wave-uniform
+    case 0: return scalar_bits_at<0>(s, sh);
+    case 1: return scalar_bits_at<1>(s, sh);
+    case 2: return scalar_bits_at<2>(s, sh);
+    case 3: return scalar_bits_at<3>(s, sh);
+    case 4: return scalar_bits_at<4>(s, sh);
+    case 5: return scalar_bits_at<5>(s, sh);
+    case 6: return scalar_bits_at<6>(s, sh);
+    case 7: return scalar_bits_at<7>(s, sh);
+    default: return 0;
+  }
+}
+// the digit of window w: `u` = its c raw bits (scalar_window(st.s, w c) & wmask)
 template <bool FOLD>
-__device__ __forceinline__ void next_digit(ScalarDigits& st, uint32_t c, uint32_t half, uint32_t wmask, bool flip, uint32_t rwin, uint32_t& mag,
-                                           bool& neg) {
-  uint32_t u = st.s[0] & wmask;
-#pragma unroll
-  for (int j = 0; j < 7; j++) st.s[j] = (st.s[j] >> c) | (st.s[j + 1] << (32 - c));
-  st.s[7] >>= c;
+__device__ __forceinline__ void next_digit(ScalarDigits& st, uint32_t u, uint32_t c, uint32_t half, uint32_t wmask, bool flip, uint32_t rwin,
+                                           uint32_t& mag, bool& neg) {
   if constexpr (FOLD) {
     const uint32_t sub = u + ((st.carry >> 1) & 1u);   // <= 2^c
     const bool borrow = flip && rwin < sub;
@@ -211,7 +252,7 @@ __global__ void __launch_bounds__(PART_THREADS) k_l1_hist(const uint32_t* __rest
     for (uint32_t w = 0; w < p.windows; w++) {
       uint32_t mag;
       bool neg;
-      next_digit<FOLD>(st, p.c, p.half, wmask, flip, FOLD ? fr_window<FR>(w, p.c, wmask) : 0u, mag, neg);
+      next_digit<FOLD>(st, scalar_window(st.s, w * p.c) & wmask, p.c, p.half, wmask, flip, FOLD ? fr_window<FR>(w, p.c, wmask) : 0u, mag, neg);
       if (w < w_lo || w >= w_hi) continue;   // (block-uniform) another block of this tile counts that window
       bool dead = dead0;
       if (have && p.table_stride) dead = inf[p.idx0 + i + w * p.table_stride] != 0;
@@ -228,7 +269,11 @@ __global__ void __launch_bounds__(PART_THREADS) k_l1_hist(const uint32_t* __rest
           few_bins_count(hist, p.b1, w * p.b1, ok, hi);
         }
       } else if (ok) {
+#ifdef PART_EXP_L1H_NOATOMIC   // diagnosis only: the digits without the LDS atomics
+        if (mag == 0x7fffffffu) hist[0] = 1;
+#else
         atomicAdd(&hist[l1_bin(p, w, mag - 1)], 1u);
+#endif
       }
     }
   }
@@ -280,7 +325,7 @@ __global__ void __launch_bounds__(1024) k_l1_scan_b(uint32_t* __restrict__ parti
     }
     uint32_t tot, tot_sj;
     const uint32_t before = block_excl_scan(col, tmp, tot);
-    const uint32_t nsj = (col + PART_SUBJOB - 1) / PART_SUBJOB;
+    const uint32_t nsj = part_subjobs_of(col);
     const uint32_t sj_before = block_excl_scan(nsj, tmp, tot_sj);
     const uint32_t base = carry_pos, base_sj = carry_sj;
     if (b < p.nbins) {
@@ -336,7 +381,7 @@ __global__ void __launch_bounds__(256) k_l1_merge_shared(const PartSeg* __restri
       start = bins[h * p.windows].start;
       for (uint32_t w = 0; w < p.windows; w++) len += bins[h * p.windows + w].len;
     }
-    const uint32_t nsj = (len + PART_SUBJOB - 1) / PART_SUBJOB;
+    const uint32_t nsj = part_subjobs_of(len);
     uint32_t tot;
     const uint32_t before = block_excl_scan(nsj, tmp, tot);
     const uint32_t base = h0 == 0 ? 0 : subjob_first[h0];
@@ -397,23 +442,35 @@ __global__ void __launch_bounds__(PART_THREADS) k_l1_scatter(const uint32_t* __r
       for (uint32_t w = 0; w < w_lo; w++) {
         uint32_t mag;
         bool neg;
-        next_digit<FOLD>(st[k], p.c, p.half, wmask, ((alive >> (8 + k)) & 1) != 0, FOLD ? fr_window<FR>(w, p.c, wmask) : 0u, mag, neg);
+        next_digit<FOLD>(st[k], scalar_window(st[k].s, w * p.c) & wmask, p.c, p.half, wmask, ((alive >> (8 + k)) & 1) != 0,
+                         FOLD ? fr_window<FR>(w, p.c, wmask) : 0u, mag, neg);
       }
     }
   }
   uint32_t offs_next = threadIdx.x < p.b1 ? row[p.shared ? threadIdx.x * p.windows + w_lo : w_lo * p.b1 + threadIdx.x] : 0;
+  if (threadIdx.x < p.b1) cnt[threadIdx.x] = 0;
+  lds_barrier();
+  // Barriers per window: after the ranking (A), two inside the scan, after the scan step (B), after staging (C).  cnt is zeroed and
+  // the run offsets are installed IN the scan step; no barrier ends a window: the next window's A orders its scan step (which
+  // rewrites tstart / offs) and its staging behind this window's copy-out.  (Seven barriers per window before.)
   for (uint32_t w = w_lo; w < w_hi; w++) {
-    if (threadIdx.x < p.b1) {
-      cnt[threadIdx.x] = 0;
-      offs[threadIdx.x] = offs_next;
-      if (w + 1 < w_hi) offs_next = row[p.shared ? threadIdx.x * p.windows + (w + 1) : (w + 1) * p.b1 + threadIdx.x];
-    }
-    __syncthreads();
     uint32_t where[PART_PER_THREAD];   // bin << 16 | rank in the tile's bin; 0xffffffff = no entry
     uint32_t low[PART_PER_THREAD];     // the bucket bits below the bin | sign << 31 (the entry's base index is recomputed when it is staged:
                                        // two registers per entry, not three -- this kernel runs at the 128-VGPR limit of a 1024-thread block;
                                        // same speed as three, same-box A/B)
     const uint32_t rwin = FOLD ? fr_window<FR>(w, p.c, wmask) : 0u;
+    uint32_t raw[PART_PER_THREAD];    // the window's bits of the eight scalars: ONE uniform branch on the word pair, eight v_alignbit
+    {
+      const uint32_t o = w * p.c, sh = o & 31;
+#define PART_RAW(L) case L: _Pragma("unroll") for (int k = 0; k < PART_PER_THREAD; k++) raw[k] = scalar_bits_at<L>(st[k].s, sh); break;
+      switch (o >> 5) {
+        PART_RAW(0) PART_RAW(1) PART_RAW(2) PART_RAW(3) PART_RAW(4) PART_RAW(5) PART_RAW(6) PART_RAW(7)
+        default:
+#pragma unroll
+          for (int k = 0; k < PART_PER_THREAD; k++) raw[k] = 0;
+      }
+#undef PART_RAW
+    }
 #pragma unroll
     for (int k = 0; k < PART_PER_THREAD; k++) {
       if ((uint32_t)k >= kmax) {
@@ -422,7 +479,7 @@ __global__ void __launch_bounds__(PART_THREADS) k_l1_scatter(const uint32_t* __r
       }
       uint32_t mag;
       bool neg;
-      next_digit<FOLD>(st[k], p.c, p.half, wmask, ((alive >> (8 + k)) & 1) != 0, rwin, mag, neg);
+      next_digit<FOLD>(st[k], raw[k] & wmask, p.c, p.half, wmask, ((alive >> (8 + k)) & 1) != 0, rwin, mag, neg);
       const uint32_t i = i0 + threadIdx.x + k * PART_THREADS;
       bool ok = ((alive >> k) & 1) && mag != 0;
       const uint32_t idx = p.idx0 + i + w * p.table_stride;
@@ -439,16 +496,21 @@ __global__ void __launch_bounds__(PART_THREADS) k_l1_scatter(const uint32_t* __r
         low[k] = (bucket & lowmask) | (neg ? 0x80000000u : 0u);   // lb <= 15
       }
     }
-    __syncthreads();
+    lds_barrier();   // A
     {
       // exclusive scan of the tile's bin counts (b1 <= 1024 = blockDim)
       const uint32_t v = threadIdx.x < p.b1 ? cnt[threadIdx.x] : 0;
       uint32_t tot;
-      const uint32_t ex = block_excl_scan(v, tmp, tot);
-      if (threadIdx.x < p.b1) tstart[threadIdx.x] = ex;
+      const uint32_t ex = block_excl_scan<false>(v, tmp, tot);
+      if (threadIdx.x < p.b1) {
+        tstart[threadIdx.x] = ex;
+        offs[threadIdx.x] = offs_next - ex;   // global position of staged slot j of this bin = offs[bin] + j: one LDS read per entry on the way out
+        cnt[threadIdx.x] = 0;
+        if (w + 1 < w_hi) offs_next = row[p.shared ? threadIdx.x * p.windows + (w + 1) : (w + 1) * p.b1 + threadIdx.x];
+      }
       if (threadIdx.x == 0) tstart[p.b1] = tot;
     }
-    __syncthreads();
+    lds_barrier();   // B
 #pragma unroll
     for (int k = 0; k < PART_PER_THREAD; k++)
       if (where[k] != 0xffffffffu) {
@@ -456,15 +518,18 @@ __global__ void __launch_bounds__(PART_THREADS) k_l1_scatter(const uint32_t* __r
         // (value = base index | sign << 31; key word while staged: the bits still unresolved with the bin above them)
         stage[tstart[where[k] >> 16] + (where[k] & 0xffffu)] = make_uint2(idx | (low[k] & 0x80000000u), (low[k] & 0xffffu) | (where[k] & 0xffff0000u));
       }
-    __syncthreads();
+    lds_barrier();   // C
     const uint32_t total = tstart[p.b1];
     for (uint32_t j = threadIdx.x; j < total; j += PART_THREADS) {
       uint2 e = stage[j];
       const uint32_t hi = e.y >> 16;
       e.y &= 0xffffu;
-      out[offs[hi] + (j - tstart[hi])] = e;
+#ifdef PART_EXP_L1_NOSTORE   // diagnosis only (tools/group_probe.sh): everything but the global store
+      if (e.x == 0x12345678u && e.y == 0x9abcu) out[0] = e;
+#else
+      out[offs[hi] + j] = e;
+#endif
     }
-    __syncthreads();
   }
 }
 
@@ -495,15 +560,21 @@ __global__ void __launch_bounds__(1024) k_pass_hist(const uint2* __restrict__ in
                                                     const uint32_t* __restrict__ subjob_first, PassPlan pp, uint32_t* __restrict__ counts) {
   __shared__ uint32_t hist[1 << PART_MAX_RB];
   const uint32_t nb = 1u << pp.rb, shift = pp.rem - pp.rb;
-  uint32_t seg, beg, end;
-  const bool live = subjob_range(segs, subjob_first, pp.nsegs, blockIdx.x, seg, beg, end);
-  if (!live) return;
-  for (uint32_t b = threadIdx.x; b < nb; b += 1024) hist[b] = 0;
-  __syncthreads();
-  for (uint32_t e = beg + threadIdx.x; e < end; e += 1024) atomicAdd(&hist[(in[e].y >> shift) & (nb - 1)], 1u);
-  __syncthreads();
-  uint32_t* row = counts + (size_t)blockIdx.x * nb;
-  for (uint32_t b = threadIdx.x; b < nb; b += 1024) row[b] = hist[b];
+  // the blocks walk the sub-jobs (none at all for a uniform input, whose segments all go to k_pass_fused: the grid is small so that
+  // finding nothing to do costs microseconds, not a block launch per possible sub-job)
+  const uint32_t nsub = subjob_first[pp.nsegs];
+  for (uint32_t j = blockIdx.x; j < nsub; j += gridDim.x) {
+    uint32_t seg, beg, end;
+    const bool live = subjob_range(segs, subjob_first, pp.nsegs, j, seg, beg, end);
+    if (!live || part_fused_takes(segs[seg].len)) continue;   // (block-uniform)
+    for (uint32_t b = threadIdx.x; b < nb; b += 1024) hist[b] = 0;
+    __syncthreads();
+    for (uint32_t e = beg + threadIdx.x; e < end; e += 1024) atomicAdd(&hist[(in[e].y >> shift) & (nb - 1)], 1u);
+    __syncthreads();
+    uint32_t* row = counts + (size_t)j * nb;
+    for (uint32_t b = threadIdx.x; b < nb; b += 1024) row[b] = hist[b];
+    __syncthreads();
+  }
 }
 
 // One block per segment: turns the count rows of its sub-jobs into positions (in place) and emits the sub-segments.
@@ -513,6 +584,7 @@ __global__ void __launch_bounds__(1024) k_pass_scan(const PartSeg* __restrict__ 
   __shared__ uint32_t tmp[32];
   const uint32_t s = blockIdx.x, nb = 1u << pp.rb, b = threadIdx.x;
   const PartSeg sg = segs[s];
+  if (part_fused_takes(sg.len)) return;
   const uint32_t j0 = subjob_first[s], j1 = subjob_first[s + 1];
   uint32_t tot_b = 0;
   if (b < nb)
@@ -540,7 +612,7 @@ __global__ void __launch_bounds__(1024) k_pass_subjobs(const PartSeg* __restrict
   __syncthreads();
   for (uint32_t s0 = 0; s0 < nsegs; s0 += 1024) {
     const uint32_t s = s0 + threadIdx.x;
-    const uint32_t nsj = s < nsegs ? (segs[s].len + PART_SUBJOB - 1) / PART_SUBJOB : 0;
+    const uint32_t nsj = s < nsegs ? part_subjobs_of(segs[s].len) : 0;
     uint32_t tot;
     const uint32_t before = block_excl_scan(nsj, tmp, tot);
     const uint32_t base = carry;
@@ -558,36 +630,43 @@ __global__ void __launch_bounds__(1024) k_pass_subjobs(const PartSeg* __restrict
 // Scatter of one sub-job: LDS multisplit tile by tile, cursors of the sub-job in LDS, runs written contiguously; the next
 // tile's entries are already in flight while the current one is split.  What bounds it is not LDS or issue but how many
 // partially written 128-B lines the XCD's 4-MB L2 has to keep open (bins x concurrent blocks): hence big tiles, one block per CU.
-__global__ void __launch_bounds__(1024, PART_PASS_OCC) k_pass_scatter(const uint2* __restrict__ in, const PartSeg* __restrict__ segs,
-                                                          const uint32_t* __restrict__ subjob_first, PassPlan pp,
-                                                          const uint32_t* __restrict__ positions, uint2* __restrict__ out) {
-  __shared__ uint2 stage[PART_PTILE];
-  __shared__ uint32_t cur[1 << PART_MAX_RB], cnt[1 << PART_MAX_RB], tstart[(1 << PART_MAX_RB) + 1];
-  __shared__ uint32_t tmp[32];
+#ifdef PART_EXP_PS_CACHEDLOAD   // diagnosis only: every block re-reads one 128-KB window (L2 hits)
+#define PART_LD(e) ((e) & 0x3fffu)
+#else
+#define PART_LD(e) (e)
+#endif
+// LDS of a scattering block: the staged tile, and per bin the cursor of the (sub-)job, the tile's count / first staged slot /
+// global position of its staged slot 0.
+struct PassLds {
+  uint2 stage[PART_PTILE];
+  uint32_t cur[1 << PART_MAX_RB], cnt[1 << PART_MAX_RB], tstart[(1 << PART_MAX_RB) + 1], dst[1 << PART_MAX_RB];
+  uint32_t tmp[32];
+};
+
+// Scatter of the entries [beg, end) of one segment; the caller has set the cursors L.cur, zeroed L.cnt and passed a barrier:
+// LDS multisplit tile by tile, runs written contiguously; the next tile's entries are already in flight while the current one
+// is split.
+__device__ __forceinline__ void pass_scatter_tiles(PassLds& L, const uint2* __restrict__ in, uint2* __restrict__ out, uint32_t beg, uint32_t end,
+                                                   const PassPlan& pp, uint32_t key_base) {
   const uint32_t nb = 1u << pp.rb, shift = pp.rem - pp.rb, keepmask = (1u << shift) - 1;
-  uint32_t seg, beg, end;
-  const bool live = subjob_range(segs, subjob_first, pp.nsegs, blockIdx.x, seg, beg, end);
-  if (!live) return;
-  const uint32_t key_base = segs[seg].key_base;
-  const uint32_t* row = positions + (size_t)blockIdx.x * nb;
-  for (uint32_t b = threadIdx.x; b < nb; b += 1024) cur[b] = row[b];
   constexpr int PER = PART_PTILE / 1024;
   uint2 nxt[PER];
 #pragma unroll
   for (int k = 0; k < PER; k++) {
     const uint32_t e = beg + threadIdx.x + k * 1024;
-    if (e < end) nxt[k] = in[e];
+    if (e < end) nxt[k] = in[PART_LD(e)];
   }
+  // Barriers per tile: after the ranking (A), two inside the scan, after the scan step (B), after staging (C).  L.cnt is zeroed and
+  // L.cur advanced IN the scan step, and there is no barrier at the end of a tile: the next tile's A orders its scan step (which
+  // rewrites tstart / dst) and its staging behind this tile's copy-out.  (Eight barriers per tile before; each one stalls 16 waves.)
   for (uint32_t t0 = beg; t0 < end; t0 += PART_PTILE) {
-    for (uint32_t b = threadIdx.x; b < nb; b += 1024) cnt[b] = 0;
     uint2 ent[PER];
 #pragma unroll
     for (int k = 0; k < PER; k++) {
       ent[k] = nxt[k];
       const uint32_t e = t0 + PART_PTILE + threadIdx.x + k * 1024;
-      if (e < end) nxt[k] = in[e];
+      if (e < end) nxt[k] = in[PART_LD(e)];
     }
-    __syncthreads();
     uint32_t where[PER];
 #pragma unroll
     for (int k = 0; k < PER; k++) {
@@ -595,38 +674,127 @@ __global__ void __launch_bounds__(1024, PART_PASS_OCC) k_pass_scatter(const uint
       where[k] = 0xffffffffu;
       if (e < end) {
         const uint32_t bin = (ent[k].y >> shift) & (nb - 1);
-        const uint32_t rank = atomicAdd(&cnt[bin], 1u);
+        const uint32_t rank = atomicAdd(&L.cnt[bin], 1u);
         where[k] = (bin << 16) | rank;
         // key word while staged: the bits still unresolved (< 2^16) with the bin above them
         ent[k].y = (ent[k].y & keepmask) | (bin << 16);
       }
     }
-    __syncthreads();
+    lds_barrier();   // A
     {
-      const uint32_t v = threadIdx.x < nb ? cnt[threadIdx.x] : 0;
+      const uint32_t v = threadIdx.x < nb ? L.cnt[threadIdx.x] : 0;
       uint32_t tot;
-      const uint32_t ex = block_excl_scan(v, tmp, tot);
-      if (threadIdx.x < nb) tstart[threadIdx.x] = ex;
-      if (threadIdx.x == 0) tstart[nb] = tot;
+      const uint32_t ex = block_excl_scan<false>(v, L.tmp, tot);
+      if (threadIdx.x < nb) {
+        const uint32_t c0 = L.cur[threadIdx.x];
+        L.tstart[threadIdx.x] = ex;
+#ifdef PART_EXP_PS_ALIGNED   // diagnosis only (wrong output): every run starts on a 128-byte line
+        L.dst[threadIdx.x] = (c0 & ~15u) - ex;
+#else
+        L.dst[threadIdx.x] = c0 - ex;   // global position of staged slot j of this bin = dst[bin] + j
+#endif
+        L.cur[threadIdx.x] = c0 + v;
+        L.cnt[threadIdx.x] = 0;
+      }
+      if (threadIdx.x == 0) L.tstart[nb] = tot;
     }
-    __syncthreads();
+    lds_barrier();   // B
 #pragma unroll
     for (int k = 0; k < PER; k++)
-      if (where[k] != 0xffffffffu) stage[tstart[where[k] >> 16] + (where[k] & 0xffffu)] = ent[k];
-    __syncthreads();
-    const uint32_t total = tstart[nb];
+      if (where[k] != 0xffffffffu) L.stage[L.tstart[where[k] >> 16] + (where[k] & 0xffffu)] = ent[k];
+    lds_barrier();   // C
+    const uint32_t total = L.tstart[nb];
     for (uint32_t j = threadIdx.x; j < total; j += 1024) {
-      uint2 e = stage[j];
+      uint2 e = L.stage[j];
       const uint32_t bin = e.y >> 16;
       // leaving: after the last pass the key word is the full key, before it the bits the next pass will look at
       e.y = pp.last ? key_base + bin : (e.y & 0xffffu);
-      out[cur[bin] + (j - tstart[bin])] = e;
+#if defined(PART_EXP_PS_NOSTORE)
+      if (e.x == 0x12345678u && e.y == 0x9abcu) out[0] = e;
+#elif defined(PART_EXP_PS_L2STORE)   // diagnosis only: the stores land in a 1-MB window (L2 hits, no HBM write traffic)
+      out[(L.dst[bin] + j) & 0x1ffffu] = e;
+#else
+      out[L.dst[bin] + j] = e;
+#endif
     }
-    __syncthreads();
-    for (uint32_t b = threadIdx.x; b < nb; b += 1024) cur[b] += cnt[b];
-    // (the zeroing of cnt at the top of the next tile is ordered behind this update by the barrier that follows it)
-    __syncthreads();
   }
+}
+
+// The scatter of a generic pass, one launch for both kinds of segment.
+//
+// Blocks [gen, gen + nsegs): one block per segment of at most PART_SUBJOB entries -- every segment of a uniform input: histogram of
+// the segment, scan, the sub-segments for the next pass, and the scatter, in one kernel.  The histogram sweep streams the segment
+// from HBM; the scatter sweep finds most of it again in L2 / the memory-side cache (512 KB per segment at 2^26 pairs), so the
+// entries cross the HBM interface once on the way in instead of twice, and no (sub-job x bin) matrix is written for them (round 4).
+//
+// Blocks [0, gen): the sub-jobs of the LONGER segments, whose positions k_pass_hist + k_pass_scan prepared (a skewed input: all
+// scalars equal puts a whole window into one segment; and the top window of any input, whose few significant bits fill only a
+// handful of level-1 bins -- 344 sub-jobs at 2^26 pairs).  They walk the sub-jobs, and they come FIRST in the grid, so that these
+// few long jobs run under the thousands of short ones instead of leaving most of the chip idle in a launch of their own.
+//
+// What bounds the scatter is not LDS or issue but how many partially written 128-B lines the XCD's 4-MB L2 has to keep open
+// (bins x concurrent blocks): hence big tiles, one block per CU.
+__global__ void __launch_bounds__(1024, PART_PASS_OCC) k_pass_scatter(const uint2* __restrict__ in, const PartSeg* __restrict__ segs,
+                                                          const uint32_t* __restrict__ subjob_first, PassPlan pp, uint32_t gen,
+                                                          const uint32_t* __restrict__ positions, uint2* __restrict__ out,
+                                                          PartSeg* __restrict__ out_segs) {
+  __shared__ PassLds L;
+  const uint32_t nb = 1u << pp.rb, shift = pp.rem - pp.rb;
+  if (blockIdx.x < gen) {
+    const uint32_t nsub = subjob_first[pp.nsegs];
+    for (uint32_t j = blockIdx.x; j < nsub; j += gen) {
+      uint32_t seg, beg, end;
+      const bool live = subjob_range(segs, subjob_first, pp.nsegs, j, seg, beg, end);
+      if (!live) continue;
+      const PartSeg sg = segs[seg];
+      if (part_fused_takes(sg.len)) continue;
+      const uint32_t* row = positions + (size_t)j * nb;
+      lds_barrier();   // the previous sub-job's copy-out still reads L
+      for (uint32_t b = threadIdx.x; b < nb; b += 1024) {
+        L.cur[b] = row[b];
+        L.cnt[b] = 0;
+      }
+      lds_barrier();
+      pass_scatter_tiles(L, in, out, beg, end, pp, sg.key_base);
+    }
+    return;
+  }
+  const uint32_t s = blockIdx.x - gen;
+  const PartSeg sg = segs[s];
+  if (!part_fused_takes(sg.len)) return;
+  if (sg.len == 0) {
+    if (out_segs)
+      for (uint32_t b = threadIdx.x; b < nb; b += 1024) out_segs[(size_t)s * nb + b] = PartSeg{sg.start, 0, sg.key_base + (b << shift), 0};
+    return;
+  }
+  const uint32_t beg = sg.start, end = sg.start + sg.len;
+  for (uint32_t b = threadIdx.x; b < nb; b += 1024) L.cnt[b] = 0;
+  lds_barrier();
+  {
+    // four loads in flight per thread
+    uint32_t e = beg + threadIdx.x;
+    for (; e + 3 * 1024 < end; e += 4 * 1024) {
+      const uint32_t k0 = in[e].y, k1 = in[e + 1024].y, k2 = in[e + 2048].y, k3 = in[e + 3072].y;
+      atomicAdd(&L.cnt[(k0 >> shift) & (nb - 1)], 1u);
+      atomicAdd(&L.cnt[(k1 >> shift) & (nb - 1)], 1u);
+      atomicAdd(&L.cnt[(k2 >> shift) & (nb - 1)], 1u);
+      atomicAdd(&L.cnt[(k3 >> shift) & (nb - 1)], 1u);
+    }
+    for (; e < end; e += 1024) atomicAdd(&L.cnt[(in[e].y >> shift) & (nb - 1)], 1u);
+  }
+  lds_barrier();
+  {
+    const uint32_t v = threadIdx.x < nb ? L.cnt[threadIdx.x] : 0;
+    uint32_t tot;
+    const uint32_t ex = block_excl_scan(v, L.tmp, tot);
+    if (threadIdx.x < nb) {
+      L.cur[threadIdx.x] = beg + ex;
+      L.cnt[threadIdx.x] = 0;
+      if (out_segs) out_segs[(size_t)s * nb + threadIdx.x] = PartSeg{beg + ex, v, sg.key_base + (threadIdx.x << shift), 0};
+    }
+  }
+  lds_barrier();
+  pass_scatter_tiles(L, in, out, beg, end, pp, sg.key_base);
 }
 
 }  // namespace msm
@@ -634,12 +802,34 @@ __global__ void __launch_bounds__(1024, PART_PASS_OCC) k_pass_scatter(const uint
 // ---- the launch sequence -------------------------------------------------------------------------------------------------------
 namespace msm {
 
+#ifndef PART_GEN_GRID
+#define PART_GEN_GRID 512u
+#endif
+// Optional per-kernel timing of one grouping run (tools/partition_test.hip): an event after every launch.
+struct PartProbe {
+  static constexpr int MAX = 32;
+  hipEvent_t ev[MAX + 1];
+  const char* name[MAX];
+  int n = 0;
+  void mark(const char* what, hipStream_t st) {
+    if (n < MAX) {
+      name[n] = what;
+      (void)hipEventRecord(ev[++n], st);
+    }
+  }
+};
+#define PART_MARK(what) do { if (probe) probe->mark(what, st); } while (0)
+
 // Enqueues the whole grouping on `st`; returns the index (0/1) of the entry buffer that holds the result.
 // `mid` (optional) is recorded after level 1 so the caller can time the two halves.
 template <class FR, bool MONT>
 inline int part_run(const uint32_t* d_scalars, const uint8_t* d_inf, const PartPlan& p, const PartBuffers& b, hipStream_t st,
-                    hipEvent_t mid, hipError_t& err) {
+                    hipEvent_t mid, hipError_t& err, PartProbe* probe = nullptr) {
   err = hipSuccess;
+  if (probe) {
+    probe->n = 0;
+    (void)hipEventRecord(probe->ev[0], st);
+  }
   const uint64_t entries = (uint64_t)p.n * p.windows;
   const dim3 scan_grid(part_ceil_div(p.nbins, 256), PART_SCAN_GROUPS);
   const uint32_t l1_grid = 8 * ((p.ntiles + 7) / 8) * p.wgroups;   // l1_tile(): a contiguous tile range per XCD; wgroups blocks per tile
@@ -647,9 +837,11 @@ inline int part_run(const uint32_t* d_scalars, const uint8_t* d_inf, const PartP
     hipLaunchKernelGGL((k_l1_hist<FR, MONT, true>), dim3(l1_grid), dim3(PART_THREADS), p.nbins * 4, st, d_scalars, d_inf, p, b.matrix);
   else
     hipLaunchKernelGGL((k_l1_hist<FR, MONT, false>), dim3(l1_grid), dim3(PART_THREADS), p.nbins * 4, st, d_scalars, d_inf, p, b.matrix);
+  PART_MARK("l1_hist");
   hipLaunchKernelGGL(k_l1_scan_a, scan_grid, dim3(256), 0, st, b.matrix, p, b.partial);
   hipLaunchKernelGGL(k_l1_scan_b, dim3(1), dim3(1024), 0, st, b.partial, p, b.segs[0], b.subjob_first, b.totals);
   hipLaunchKernelGGL(k_l1_scan_c, scan_grid, dim3(256), 0, st, b.matrix, p, b.partial);
+  PART_MARK("l1_scan");
   int seg_cur = 0;
   uint64_t nsegs = p.nbins;
   if (p.shared) {
@@ -661,6 +853,7 @@ inline int part_run(const uint32_t* d_scalars, const uint8_t* d_inf, const PartP
     hipLaunchKernelGGL((k_l1_scatter<FR, MONT, true>), dim3(l1_grid), dim3(PART_THREADS), 0, st, d_scalars, d_inf, p, b.matrix, b.entries[0]);
   else
     hipLaunchKernelGGL((k_l1_scatter<FR, MONT, false>), dim3(l1_grid), dim3(PART_THREADS), 0, st, d_scalars, d_inf, p, b.matrix, b.entries[0]);
+  PART_MARK("l1_scatter");
   if (mid) (void)hipEventRecord(mid, st);
   uint32_t rb[4];
   const int np = part_pass_bits(p.lb, rb);
@@ -674,10 +867,20 @@ inline int part_run(const uint32_t* d_scalars, const uint8_t* d_inf, const PartP
     pp.last = (i == np - 1) ? 1 : 0;
     pp.max_subjobs = part_max_subjobs(entries, nsegs);
     PartSeg* out_segs = pp.last ? nullptr : b.segs[seg_cur ^ 1];
-    hipLaunchKernelGGL(k_pass_hist, dim3(pp.max_subjobs), dim3(1024), 0, st, b.entries[cur], b.segs[seg_cur], b.subjob_first, pp, b.counts);
-    hipLaunchKernelGGL(k_pass_scan, dim3(pp.nsegs), dim3(1024), 0, st, b.segs[seg_cur], b.subjob_first, pp, b.counts, out_segs);
-    hipLaunchKernelGGL(k_pass_scatter, dim3(pp.max_subjobs), dim3(1024), 0, st, b.entries[cur], b.segs[seg_cur], b.subjob_first, pp, b.counts,
-                       b.entries[cur ^ 1]);
+    // no segment can hold more entries than its window has scalars (all windows together when they share their buckets): below
+    // PART_SUBJOB there are no long segments, hence no sub-jobs, and k_pass_hist / k_pass_scan have nothing to prepare
+    const bool long_segs = !part_fused_takes((uint32_t)std::min<uint64_t>((uint64_t)p.n * (p.shared ? p.windows : 1), 0xffffffffu));
+    const uint32_t gen = long_segs ? std::min<uint32_t>(pp.max_subjobs, PART_GEN_GRID) : 0;
+    if (long_segs) {
+      hipLaunchKernelGGL(k_pass_hist, dim3(std::min<uint32_t>(pp.max_subjobs, 2048u)), dim3(1024), 0, st, b.entries[cur], b.segs[seg_cur], b.subjob_first, pp,
+                         b.counts);
+      PART_MARK("pass_hist");
+      hipLaunchKernelGGL(k_pass_scan, dim3(pp.nsegs), dim3(1024), 0, st, b.segs[seg_cur], b.subjob_first, pp, b.counts, out_segs);
+      PART_MARK("pass_scan");
+    }
+    hipLaunchKernelGGL(k_pass_scatter, dim3(gen + pp.nsegs), dim3(1024), 0, st, b.entries[cur], b.segs[seg_cur], b.subjob_first, pp, gen, b.counts,
+                       b.entries[cur ^ 1], out_segs);
+    PART_MARK("pass_scatter");
     cur ^= 1;
     rem -= rb[i];
     if (!pp.last) {

@@ -121,8 +121,20 @@ inline int part_pass_bits(uint32_t lb, uint32_t (&rb)[4]) {
   return np;
 }
 
+// A segment of at most PART_SUBJOB entries is ONE job with nothing to coordinate between blocks: the fused kernel (k_pass_fused)
+// takes it whole -- every segment of a uniform input -- and it counts NO sub-jobs; only longer segments (a skewed input: all
+// scalars equal puts a whole window into one segment) are cut into sub-jobs for the three generic kernels.
+#ifdef PART_NO_FUSED_PASS
+__host__ __device__ inline bool part_fused_takes(uint32_t) { return false; }
+__host__ __device__ inline uint32_t part_subjobs_of(uint32_t len) { return (len + PART_SUBJOB - 1) / PART_SUBJOB; }
 // Upper bound of the sub-jobs of a pass over `nsegs` segments holding `entries` entries in total.
 inline uint32_t part_max_subjobs(uint64_t entries, uint64_t nsegs) { return (uint32_t)(entries / PART_SUBJOB + nsegs + 1); }
+#else
+__host__ __device__ inline bool part_fused_takes(uint32_t len) { return len <= PART_SUBJOB; }
+__host__ __device__ inline uint32_t part_subjobs_of(uint32_t len) { return len > PART_SUBJOB ? (len + PART_SUBJOB - 1) / PART_SUBJOB : 0; }
+// Upper bound of the sub-jobs of a pass: a segment that has any is longer than PART_SUBJOB, so it has fewer than 2 len / PART_SUBJOB.
+inline uint32_t part_max_subjobs(uint64_t entries, uint64_t /*nsegs*/) { return (uint32_t)(2 * entries / PART_SUBJOB + 2); }
+#endif
 
 // Device scratch the grouping needs besides the two entry buffers; sizes in bytes for a plan.
 struct PartScratchSizes {

@@ -106,6 +106,7 @@ def load_library() -> ctypes.CDLL:
         "mi355_msm_stream_query": [vp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_uint64)],
         "mi355_msm_stream_destroy": [vp],
         "mi355_msm_trim": [],
+        "mi355_msm_pool_stats": [ctypes.POINTER(ctypes.c_uint64), sz],
     }
     for name, args in sigs.items():
         fn = getattr(lib, name)
@@ -349,6 +350,18 @@ def last_stateless() -> dict:
     _check(load_library().mi355_msm_last_stateless(v, 8))
     names = ("total_ms", "setup_ms", "wait_upload_ms", "compute_ms", "tail_ms", "slices", "threads", "bytes")
     return {k: float(v[i]) for i, k in enumerate(names)}
+
+
+def trim() -> None:
+    """Give back what the stateless entry points keep between calls (pinned rings, idle contexts): mi355_msm_trim."""
+    _check(load_library().mi355_msm_trim())
+
+
+def pool_stats() -> dict:
+    """mi355_msm_pool_stats: idle contexts of the stateless path and the memory they hold."""
+    v = (ctypes.c_uint64 * 4)()
+    _check(load_library().mi355_msm_pool_stats(v, 4))
+    return {"idle_contexts": int(v[0]), "idle_device_bytes": int(v[1]), "idle_rings": int(v[2]), "idle_pinned_bytes": int(v[3])}
 
 
 class VariableBaseMSM:

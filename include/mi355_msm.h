@@ -183,7 +183,13 @@ RustError mi355_msm(int curve, void* out_projective, const void* affine, size_t 
  * ring, threads), ms the compute side waited for uploads, ms it spent issuing/awaiting slices, the last slice's share of that
  * (the tail nothing overlaps), slices, staging threads, bytes moved. */
 RustError mi355_msm_last_stateless(double* out, size_t count);
+/* What the stateless entry points keep between calls, and its bounds: the pinned staging rings (12 x 16 MiB per device in use) and at
+ * most ONE idle context per (curve, device) with its device buffers (~9 GB after a 2^26-pair G1 call; a context above
+ * MI355_MSM_STATELESS_KEEP_MB, default 16384, is parked without its buffers).  Any device allocation of this library that runs out
+ * of memory frees the idle contexts and retries before it fails.  mi355_msm_trim() frees rings and idle contexts now;
+ * mi355_msm_pool_stats: out[0] = idle contexts, out[1] = device bytes they hold, out[2] = idle rings, out[3] = pinned bytes they hold. */
 RustError mi355_msm_trim(void);
+RustError mi355_msm_pool_stats(uint64_t* out, size_t count);
 
 /* ---- arkworks' streaming accumulators (ARK ec/src/msm/variable_base/stream_pippenger.rs) ---------------------------------
  * ChunkedPippenger::{new, with_size, add, finalize} (:11-75) and HashMapPippenger::{new, add, finalize} (:78-140): what a prover

@@ -117,6 +117,7 @@ pub mod sys {
         pub fn mi355_msm_shard_timings(ctx: *mut c_void, shard: c_int, ms: *mut f32, info: *mut u64) -> Error;
         pub fn mi355_msm_last_stateless(out: *mut f64, count: usize) -> Error;
         pub fn mi355_msm_trim() -> Error;
+        pub fn mi355_msm_pool_stats(out: *mut u64, count: usize) -> Error;
         // arkworks' streaming accumulators (ark-ec stream_pippenger.rs) over the engine
         pub fn mi355_msm_stream_create(out: *mut *mut c_void, curve: c_int, device: c_int, max_msm_buffer: usize, hashmap: c_int) -> Error;
         pub fn mi355_msm_stream_set_option(s: *mut c_void, key: *const c_char, value: c_long) -> Error;

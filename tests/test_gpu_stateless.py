@@ -177,3 +177,123 @@ def test_calls_leave_the_current_device_alone(ea, oracle):
         assert torch.cuda.current_device() == 0
     # a tensor allocated now lands on device 0
     assert torch.zeros(1, device="cuda").device.index == 0
+
+
+def test_concurrent_stateless_calls_and_the_pool_bound(ea, oracle):
+    """Two HOST THREADS inside mi355_msm() at once (ctypes drops the GIL): each leases its own context, ring and copy stream
+    (csrc/msm_stateless.hpp:StatelessLease / ring_acquire; so far only raced under ThreadSanitizer against a fake copy engine,
+    tests/tsan_pipeline.cpp) -- both results equal the oracle, several rounds, different sizes and curves in flight together.
+    Afterwards the pool holds ONE idle context per (curve, device), not one per caller, mi355_msm_pool_stats reports
+    it, and mi355_msm_trim() empties it."""
+    import threading
+
+    ea.trim()
+    assert ea.pool_stats()["idle_contexts"] == 0
+    jobs = []
+    for t, (curve, cid, n) in enumerate((("bls12_377_g1", 0, 60001), ("bls12_377_g1", 0, 1 << 16), ("bls12_381_g1", 1, 40000), ("bls12_377_g1", 0, 3000))):
+        bases = ea.generate_points(n, distinct=max(1, n // 5), seed=100 + t, curve=curve)
+        sc = _scalars(n, 200 + t)
+        jobs.append((curve, cid, n, bases, sc, oracle_msm_np(oracle, cid, bases, sc, n)))
+    errors = []
+
+    def worker(job, rounds):
+        curve, cid, n, bases, sc, exp = job
+        try:
+            for _ in range(rounds):
+                got = ea.msm(bases, sc, curve)
+                if got != exp:
+                    errors.append((curve, n, "result differs from the oracle"))
+        except Exception as e:   # noqa: BLE001
+            errors.append((curve, n, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(job, 4)) for job in jobs]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(timeout=600)
+    assert not errors, errors
+    st = ea.pool_stats()
+    # three callers used bls12_377_g1 on this device at the same time, one bls12_381_g1: one parked context per key
+    assert st["idle_contexts"] == 2, st
+    assert st["idle_rings"] >= 1 and st["idle_pinned_bytes"] == st["idle_rings"] * 12 * (16 << 20)
+    ea.trim()
+    assert ea.pool_stats() == {"idle_contexts": 0, "idle_device_bytes": 0, "idle_rings": 0, "idle_pinned_bytes": 0}
+
+
+def test_idle_context_gives_its_buffers_back_above_the_threshold(ea, oracle):
+    """MI355_MSM_STATELESS_KEEP_MB bounds what a parked context may hold: 0 parks it without device buffers; the next call still works."""
+    n = 50000
+    bases = ea.generate_points(n, distinct=5000, seed=77)
+    sc = _scalars(n, 78)
+    exp = oracle_msm_np(oracle, 0, bases, sc, n)
+    ea.trim()
+    assert ea.msm(bases, sc) == exp
+    held = ea.pool_stats()["idle_device_bytes"]
+    assert held > n * 100                                   # bases, scalars, raw records and work buffers stay with the parked context
+    with _Env(MI355_MSM_STATELESS_KEEP_MB=0):
+        assert ea.msm(bases, sc) == exp
+        st = ea.pool_stats()
+        assert st["idle_contexts"] == 1 and st["idle_device_bytes"] < held // 4, (st, held)
+        assert ea.msm(bases, sc) == exp
+    ea.trim()
+
+
+def test_out_of_memory_reclaims_the_idle_contexts_first(ea, oracle):
+    """An allocation that does not fit frees the parked stateless contexts and retries before anything fails or shrinks
+    (DevBuf::reserve -> reclaim_idle_device_memory): park a context, then ask a NEW context for almost all of the device."""
+    import torch
+
+    n = 1 << 16
+    bases = ea.generate_points(n, distinct=4096, seed=5)
+    sc = _scalars(n, 6)
+    exp = oracle_msm_np(oracle, 0, bases, sc, n)
+    ea.trim()
+    assert ea.msm(bases, sc) == exp
+    assert ea.pool_stats()["idle_contexts"] == 1
+    free_b, _total = torch.cuda.mem_get_info()
+    hog = torch.empty(max(1, free_b - (16 << 20)), dtype=torch.uint8, device="cuda")    # leave 16 MiB: less than the context below needs
+    try:
+        ctx = ea.multi_scalar_mult_init(bases, "bls12_377_g1")
+        assert ctx.run(sc)[0] == exp
+        backoffs = ctx.query("oom_backoffs")
+        ctx.close()
+    finally:
+        del hog
+        torch.cuda.empty_cache()
+    assert ea.pool_stats()["idle_contexts"] == 0, "the parked context should have been reclaimed by the failing allocation"
+    assert backoffs >= 0
+
+
+def test_concurrent_streaming_accumulators(ea, oracle):
+    """Two ChunkedPippenger objects flushing from two host threads at once (every flush is a stateless pipeline run)."""
+    import threading
+
+    jobs = []
+    for t in range(2):
+        n = 7000 + 1500 * t
+        bases = ea.generate_points(n, distinct=300, seed=40 + t)
+        sc = _scalars(n, 50 + t)
+        jobs.append((n, bases, sc, oracle_msm_np(oracle, 0, bases, sc, n)))
+    errors = []
+
+    def worker(job):
+        n, bases, sc, exp = job
+        try:
+            cp = ea.ChunkedPippenger(1000)
+            for lo in range(0, n, 777):
+                cp.add(bases[lo:lo + 777], sc[lo:lo + 777])
+            got = cp.finalize()
+            flushes = cp.query("flushes")
+            cp.close()
+            if got != exp or flushes < n // 1000:
+                errors.append((n, "mismatch", flushes))
+        except Exception as e:   # noqa: BLE001
+            errors.append((n, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(j,)) for j in jobs]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(timeout=600)
+    assert not errors, errors
+    ea.trim()

@@ -90,7 +90,8 @@ def test_new_entry_points_are_declared_in_the_crate_and_exported(built):
     SURVEY.md section 8(b) asks for: the literal `msm`, and the yrrid hex readers."""
     items = _extern_items(open(os.path.join(RUST, "src", "lib.rs")).read())
     for name in ("mi355_msm_stream_create", "mi355_msm_stream_add", "mi355_msm_stream_finalize", "mi355_msm_stream_destroy",
-                 "mi355_msm_stream_set_option", "mi355_msm_stream_query", "mi355_msm_last_stateless", "mi355_msm_trim", "mi355_msm_shard_timings"):
+                 "mi355_msm_stream_set_option", "mi355_msm_stream_query", "mi355_msm_last_stateless", "mi355_msm_trim", "mi355_msm_pool_stats",
+                 "mi355_msm_shard_timings"):
         assert name in items, name
     for cv in ("377", "381"):
         assert "msm" in _exports(os.path.join(PKG, f"libmi355msm_msm_{cv}.so"))

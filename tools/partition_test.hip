@@ -90,6 +90,10 @@ int main(int argc, char** argv) {
   CHECK(hipMalloc(&b.subjob_first, sz.subjob_first)); CHECK(hipMalloc(&b.counts, sz.counts)); CHECK(hipMalloc(&b.totals, sz.totals));
   hipStream_t st; CHECK(hipStreamCreate(&st));
   hipEvent_t e0, e1, em; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1)); CHECK(hipEventCreate(&em));
+  PartProbe probe;
+  for (int i = 0; i <= PartProbe::MAX; i++) CHECK(hipEventCreate(&probe.ev[i]));
+  float kbest[PartProbe::MAX];
+  for (float& v : kbest) v = 1e30f;
   int res = 0;
   float best = 1e30f, best_l1 = 0;
   for (int r = 0; r < reps; r++) {
@@ -97,10 +101,15 @@ int main(int argc, char** argv) {
     CHECK(hipMemsetAsync(b.entries[1], 0xff, E * 8, st));
     CHECK(hipEventRecord(e0, st));
     hipError_t err;
-    res = part_run<Bls12_377_Fr, false>(d_sc, d_inf, p, b, st, em, err);
+    res = part_run<Bls12_377_Fr, false>(d_sc, d_inf, p, b, st, em, err, &probe);
     CHECK(err);
     CHECK(hipEventRecord(e1, st));
     CHECK(hipStreamSynchronize(st));
+    for (int i = 0; i < probe.n; i++) {
+      float k;
+      CHECK(hipEventElapsedTime(&k, probe.ev[i], probe.ev[i + 1]));
+      if (k < kbest[i]) kbest[i] = k;
+    }
     float ms, ms1; CHECK(hipEventElapsedTime(&ms, e0, e1)); CHECK(hipEventElapsedTime(&ms1, e0, em));
     if (ms < best) { best = ms; best_l1 = ms1; }
   }
@@ -108,6 +117,10 @@ int main(int argc, char** argv) {
   CHECK(hipMemcpy(totals, b.totals, 8, hipMemcpyDeviceToHost));
   printf("grouping: %.3f ms (level 1 incl. histogram + scan %.3f ms), %u real entries of %llu (%.2f G entries/s)\n", best, best_l1, totals[0],
          (unsigned long long)E, E / best / 1e6);
+  printf("generic sub-jobs of the last pass: %u\n", totals[1]);
+  printf("per kernel (best of %d, ms):", reps);
+  for (int i = 0; i < probe.n; i++) printf("  %s %.3f", probe.name[i], kbest[i]);
+  printf("\n");
   int bad = 0;
   if (model) {
     std::vector<uint2> out(totals[0]);
