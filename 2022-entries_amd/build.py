@@ -1,6 +1,7 @@
 """Build the native pieces in-tree (the .so files are git-ignored but travel with the gpurun snapshot).
 
   libmi355msm.so       hipcc --offload-arch=gfx950: kernels + engine + C ABI (the product)
+  libmi355msm_debug.so the same with -DMSM_DEBUG on the engine and grouping units: device-side invariant checks (tests only)
   libmsm_hosttest.so   g++: the same fp28/curve templates for the host with the limb-bound checker (tests only)
   libmsm_devtest.so    hipcc: the same templates as element-wise test kernels (tests only)
   oracle/liboracle.so  gcc: CPU restatement of the arkworks algorithm (tests / smoke / bench cpu_baseline only)
@@ -85,6 +86,39 @@ def build_engine(force: bool = False) -> str:
     return out
 
 
+def build_debug_engine(force: bool = False) -> str:
+    """libmi355msm_debug.so (tests only): the host orchestration and the grouping unit compiled with -DMSM_DEBUG -- invariant checks
+    after every grouping level and after the accumulation (csrc/partition.hpp; the reference keeps such a self-check, disabled, in
+    CMB Partition4096.cu:419-432) -- linked with the SAME kernel objects as the product.  tests/test_gpu_debug_build.py runs it."""
+    out = os.path.join(PKG, "libmi355msm_debug.so")
+    objdir = os.path.join(PKG, "build", "debug")
+    os.makedirs(objdir, exist_ok=True)
+    cc = hipcc()
+    headers = [f for f in glob.glob(os.path.join(CSRC, "*")) if not f.endswith(".hip") and os.path.isfile(f)]
+    jobs, objs = [], []
+    for unit in ENGINE_UNITS:
+        if unit not in ("msm_engine.hip", "partition.hip"):
+            objs.append(os.path.join(PKG, "build", unit.replace(".hip", ".o")))
+            continue
+        src = os.path.join(CSRC, unit)
+        obj = os.path.join(objdir, unit.replace(".hip", ".o"))
+        dfile = obj + ".d"
+        objs.append(obj)
+        deps = _depfile_deps(dfile)
+        if deps is None or not all(os.path.exists(d) for d in deps):
+            deps = headers + [src] + glob.glob(os.path.join(ROOT, "include", "*.h"))
+        if force or _newer(obj, deps):
+            cmd = [cc, "--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-DMSM_DEBUG", "-MD", "-MF", dfile, "-c", src, "-o", obj]
+            print("+", " ".join(cmd), flush=True)
+            jobs.append((unit, subprocess.Popen(cmd)))
+    failed = [unit for unit, pr in jobs if pr.wait() != 0]
+    if failed:
+        raise RuntimeError("hipcc failed for (debug) " + ", ".join(failed))
+    if force or jobs or _newer(out, objs):
+        _run([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)
+    return out
+
+
 def build_hosttest(force: bool = False) -> str:
     out = os.path.join(PKG, "libmsm_hosttest.so")
     deps = glob.glob(os.path.join(CSRC, "*"))
@@ -127,6 +161,7 @@ def build_oracle() -> str:
 
 def build_all(force: bool = False) -> None:
     build_engine(force)
+    build_debug_engine(force)
     build_hosttest(force)
     build_devtest(force)
     build_shims(force)

@@ -56,6 +56,10 @@ struct LaunchTe {
 struct PartLaunch {
   static int run(int scalar_field, bool montgomery, const uint32_t* d_scalars, const uint8_t* d_inf, const PartPlan& p, const PartBuffers& b,
                  hipStream_t st, hipEvent_t mid, hipError_t& err);
+  // -DMSM_DEBUG builds only (otherwise a no-op that reports nothing): the slot-key check after the accumulation, then the stream is
+  // synchronised and the violation counters of this chunk are read -- what[] names the first violated invariant, empty = all held.
+  static hipError_t debug_finish(const PartPlan& p, const PartBuffers& b, const uint32_t* slot_keys, uint32_t nslots, hipStream_t st, char* what,
+                                 size_t what_len, uint64_t* checks_done);
 };
 
 extern template struct Launch<Bls12_377_G1::E>;

@@ -226,6 +226,7 @@ struct mi355_msm_ctx {
   uint32_t te_fallback_streak = 0;   // consecutive chunks that fell back; two in a row demote the context to XYZZ for good
   uint64_t te_demotions = 0;
   uint64_t oom_backoffs = 0;      // chunks restarted with half the chunk size after a device allocation failed
+  uint64_t debug_checks = 0;      // -DMSM_DEBUG builds: invariant checks run so far (csrc/partition.hpp)
   size_t chunk_cap = 0;           // what the most recent run had to cap its chunks at after an allocation failed (0 = it never had to); reported, not kept
   size_t fitted_chunk = 0;        // largest chunk that has run with the current buffers and options (skips the fit query)
   bool fitted_tables = false;
@@ -724,6 +725,14 @@ bool run_chunk_impl(mi355_msm_ctx* ctx, const uint32_t* d_scalars, size_t base0,
   else
     HIP_OK(Launch<E>::accumulate(entries, n_real, p.K, bases, so, p.nlanes, st));
   HIP_OK(hipEventRecord(ev[3], st));
+#ifdef MSM_DEBUG
+  {
+    // the debug build stops here after every chunk: the grouping's violation counters and the slot keys the accumulation left
+    char what[320];
+    HIP_OK(PartLaunch::debug_finish(gp, gb, ctx->slot_keys[0].as<uint32_t>(), 2 * p.nlanes, st, what, sizeof what, &ctx->debug_checks));
+    if (what[0]) throw HipFailure(-2, what);
+  }
+#endif
 
   // merge the run fragments that crossed lane boundaries
   uint32_t n_in = 2 * p.nlanes;
@@ -1006,6 +1015,29 @@ void run_device_t(mi355_msm_ctx* ctx, uint8_t* out, const uint32_t* d_scalars, s
         carry.c = ctx->plan(std::min(n, (size_t)1 << 26), tables_now).c;
         carry.index = 0;
         fit();                                  // ... under which a chunk needs other buffers
+        if (split && !ctx->opt_mem_limit) {
+          // The pieces of the first host-scalar batch GROW (1/13, 3/13, 9/13): sized chunk by chunk, every larger piece would free
+          // and re-allocate the entry / slot / grouping buffers on a context's first run, and hipFree is a device synchronisation
+          // while the previous piece's kernels are still queued.  One reservation for the largest need of any piece.
+          WorkBytes w;
+          bool fits = true;
+          for (size_t i = 0; i < P; i++) {
+            const size_t cnt = std::min(max_chunk, pb[i + 1] - pb[i]);
+            if (!cnt) continue;
+            const Plan pl = ctx->plan(cnt, tables_now, carry.c);
+            fits = fits && pl.entries < (1ull << 32);
+            w.max_with(chunk_work_bytes(pl, cnt, tables_now, sizeof(XyzzDevT<typename E::T>), true));
+          }
+          if (fits) {
+            try {
+              reserve_work(ctx, w);
+            } catch (const HipFailure& e) {
+              if (e.code != (int)hipErrorOutOfMemory) throw;
+              release_work_buffers(ctx);   // short of memory: the per-chunk fit / back-off below sizes the chunks
+              fit();
+            }
+          }
+        }
       }
       const bool last = off + cn >= n;
       if (split && !awaited[piece]) {
@@ -1026,6 +1058,8 @@ void run_device_t(mi355_msm_ctx* ctx, uint8_t* out, const uint32_t* d_scalars, s
         if (e.code != (int)hipErrorOutOfMemory || cn <= 1024) throw;
         (void)hipStreamSynchronize(st);
         release_work_buffers(ctx, carried && off > 0);
+        // memory this library still holds behind the caller's back (parked stateless contexts) goes first: same chunk again
+        if (reclaim_idle_device_memory()) continue;
         max_chunk = ctx->chunk_cap = (cn + 1) / 2;   // for the rest of this run
         ctx->oom_backoffs++;
         continue;
@@ -1456,6 +1490,8 @@ RustError mi355_msm_query(mi355_msm_ctx* ctx, const char* key, uint64_t* value) 
       *value = ctx->opt_carry ? 1 : 0;
     else if (k == "oom_backoffs")
       *value = ctx->oom_backoffs;
+    else if (k == "debug_checks")   // invariant checks a -DMSM_DEBUG build has run on this context (always 0 in the product build)
+      *value = ctx->debug_checks;
     else if (k == "chunk_cap")
       *value = ctx->chunk_cap;
     else if (k == "device")
@@ -1490,8 +1526,12 @@ RustError mi355_msm(int curve, void* out, const void* affine, size_t npoints, co
       }
     }
     const size_t G = devs.size(), pb = 3 * coord_bytes(curve);
+    // MI355_MSM_ASSUME_SUBGROUP applies here as it does to mi355_msm_create_env (a pooled context keeps no option of an earlier call)
+    const char* sub_env = getenv("MI355_MSM_ASSUME_SUBGROUP");
+    const long assume_sub = (sub_env && *sub_env && atol(sub_env) != 0) ? 1 : 0;
     if (G == 1) {
       StatelessLease ws(curve, devs[0]);
+      take(mi355_msm_set_option(ws.ctx, "assume_subgroup", assume_sub));
       stateless_run(ws.ctx, out, affine, npoints, scalars, ffi_affine_sz);
       ws.keep();
       return;
@@ -1507,6 +1547,7 @@ RustError mi355_msm(int curve, void* out, const void* affine, size_t npoints, co
           size_t lo, hi;
           shard_bounds(npoints, G, g, lo, hi);
           StatelessLease ws(curve, devs[g]);
+          take(mi355_msm_set_option(ws.ctx, "assume_subgroup", assume_sub));
           stateless_run(ws.ctx, partials.data() + g * pb, (const uint8_t*)affine + lo * ffi_affine_sz, hi - lo, (const uint8_t*)scalars + lo * 32,
                         ffi_affine_sz);
           ws.keep();
@@ -1636,7 +1677,11 @@ RustError mi355_msm_shard_bounds(size_t npoints, int nshards, int shard, size_t*
   });
 }
 
-const char* mi355_msm_version(void) { return "mi355-msm 0.3 (gfx950)"; }
+#ifdef MSM_DEBUG
+const char* mi355_msm_version(void) { return "mi355-msm 0.4 (gfx950) +debug-invariants"; }
+#else
+const char* mi355_msm_version(void) { return "mi355-msm 0.4 (gfx950)"; }
+#endif
 
 }  // extern "C"
 

@@ -337,6 +337,7 @@ void stateless_t(mi355_msm_ctx* ctx, uint8_t* out, const uint8_t* affine, size_t
             if (e.code != (int)hipErrorOutOfMemory || cn <= 1024) throw;
             (void)hipStreamSynchronize(st);
             release_work_buffers(ctx, carry_c && !carry.first);   // (the totals of the slices so far stay)
+            if (reclaim_idle_device_memory()) continue;           // parked contexts of other curves / devices go first
             max_chunk = ctx->chunk_cap = (cn + 1) / 2;
             ctx->oom_backoffs++;
             continue;

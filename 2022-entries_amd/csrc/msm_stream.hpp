@@ -88,17 +88,20 @@ void stream_flush(mi355_msm_stream* s) {
   memcpy(two.data(), s->result.data(), pb);
   {
     StatelessLease ws(s->curve, s->device);
-    ws.ctx->opt_scalars_montgomery = s->opt_scalars_montgomery;
-    ws.ctx->opt_window_bits = s->opt_window_bits;
-    try {
-      stateless_run(ws.ctx, two.data() + pb, s->bases.data(), n, s->scalars.data(), s->stride);
-    } catch (...) {
-      ws.ctx->opt_scalars_montgomery = 0;
-      ws.ctx->opt_window_bits = 0;
-      throw;
-    }
-    ws.ctx->opt_scalars_montgomery = 0;   // the context goes back to the pool of the plain stateless call
-    ws.ctx->opt_window_bits = 0;
+    // through set_option (its validation, its reset of the fitted chunk), and back to the defaults on every way out: the context
+    // returns to the pool of the plain stateless call
+    struct Restore {
+      mi355_msm_ctx* c;
+      ~Restore() {
+        for (const char* k : {"scalars_montgomery", "window_bits"}) {
+          RustError e = mi355_msm_set_option(c, k, 0);
+          if (e.message) free(e.message);
+        }
+      }
+    } restore{ws.ctx};
+    take(mi355_msm_set_option(ws.ctx, "scalars_montgomery", s->opt_scalars_montgomery));
+    take(mi355_msm_set_option(ws.ctx, "window_bits", s->opt_window_bits));
+    stateless_run(ws.ctx, two.data() + pb, s->bases.data(), n, s->scalars.data(), s->stride);
     ws.keep();
   }
   take(mi355_msm_fold(s->curve, s->result.data(), two.data(), 2));

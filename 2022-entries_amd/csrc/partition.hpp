@@ -802,6 +802,91 @@ __global__ void __launch_bounds__(1024, PART_PASS_OCC) k_pass_scatter(const uint
 // ---- the launch sequence -------------------------------------------------------------------------------------------------------
 namespace msm {
 
+#ifdef MSM_DEBUG
+// ---- invariant checks of the debug build (-DMSM_DEBUG: tools/build_debug.sh, tests/test_gpu_debug_build.py) -----------------------
+// The reference keeps a (disabled) prefix / count self-check in its partition ("super useful debugging code for catching race
+// conditions", CMB Partition4096.cu:419-432).  Here: after level 1 and after every pass the segment table must be contiguous and
+// end at the entry total, and every entry of a segment must carry only the key bits still unresolved; after the last pass the keys
+// must be non-decreasing, below the key limit, and the values must name bases of this chunk; the number of entries must equal the
+// number of non-zero digits, counted independently by shifting the whole scalar down window by window (NOT by scalar_window);
+// after the accumulation every slot key must be KEY_NONE or a valid key.  Violations are COUNTED into totals[4 + i]:
+enum { DBG_DIGITS = 0, DBG_SEG_GAP = 1, DBG_SEG_END = 2, DBG_KEY_BITS = 3, DBG_UNSORTED = 4, DBG_KEY_RANGE = 5, DBG_VALUE_RANGE = 6,
+       DBG_SLOT_KEY = 7, DBG_CHECKS = 8, DBG_WORDS = 12 };
+
+template <class FR, bool MONT, bool FOLD>
+__global__ void __launch_bounds__(256) k_dbg_count_digits(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ inf, PartPlan p,
+                                                          uint32_t* __restrict__ dbg) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  uint32_t count = 0;
+  if (i < p.n) {
+    ScalarDigits st;
+    load_scalar<FR, MONT>(st, scalars, i);
+    const bool flip = FOLD ? fold_decision<FR>(st) : false;
+    const uint32_t wmask = (1u << p.c) - 1;
+    for (uint32_t w = 0; w < p.windows; w++) {
+      const uint32_t u = st.s[0] & wmask;                 // the plain way: low bits, then the whole scalar down by c
+      for (int j = 0; j < 7; j++) st.s[j] = (st.s[j] >> p.c) | (st.s[j + 1] << (32 - p.c));
+      st.s[7] >>= p.c;
+      uint32_t mag;
+      bool neg;
+      next_digit<FOLD>(st, u, p.c, p.half, wmask, flip, FOLD ? fr_window<FR>(w, p.c, wmask) : 0u, mag, neg);
+      const bool dead = inf[p.idx0 + i + w * p.table_stride] != 0;
+      if (mag != 0 && !dead) count++;
+    }
+  }
+  for (int d = 32; d > 0; d >>= 1) count += __shfl_down(count, d, 64);
+  if ((threadIdx.x & 63) == 0 && count) atomicAdd(&dbg[DBG_DIGITS], count);
+}
+
+// one block per segment: contiguity of the table, and only `rem` key bits left in its entries
+__global__ void __launch_bounds__(256) k_dbg_check_level(const uint2* __restrict__ entries, const PartSeg* __restrict__ segs, uint32_t nsegs, uint32_t rem,
+                                                         const uint32_t* __restrict__ totals, uint32_t* __restrict__ dbg) {
+  const uint32_t s = blockIdx.x;
+  const PartSeg sg = segs[s];
+  if (threadIdx.x == 0) {
+    const uint32_t expect = s ? segs[s - 1].start + segs[s - 1].len : 0u;
+    if (sg.start != expect) atomicAdd(&dbg[DBG_SEG_GAP], 1u);
+    if (s + 1 == nsegs && sg.start + sg.len != totals[0]) atomicAdd(&dbg[DBG_SEG_END], 1u);
+  }
+  uint32_t bad = 0;
+  for (uint32_t e = sg.start + threadIdx.x; e < sg.start + sg.len; e += 256)
+    if (rem < 32 && (entries[e].y >> rem) != 0) bad++;
+  if (bad) atomicAdd(&dbg[DBG_KEY_BITS], bad);
+}
+
+__global__ void __launch_bounds__(256) k_dbg_check_sorted(const uint2* __restrict__ entries, const uint32_t* __restrict__ totals, uint32_t key_limit,
+                                                          uint32_t idx_lo, uint32_t idx_hi, uint32_t* __restrict__ dbg) {
+  const uint32_t n = totals[0];
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const uint2 e = entries[i];
+    if (i + 1 < n && entries[i + 1].y < e.y) atomicAdd(&dbg[DBG_UNSORTED], 1u);
+    if (e.y >= key_limit) atomicAdd(&dbg[DBG_KEY_RANGE], 1u);
+    const uint32_t idx = e.x & 0x7fffffffu;
+    if (idx < idx_lo || idx >= idx_hi) atomicAdd(&dbg[DBG_VALUE_RANGE], 1u);
+  }
+}
+
+__global__ void __launch_bounds__(256) k_dbg_check_slots(const uint32_t* __restrict__ keys, uint32_t n, uint32_t key_limit, uint32_t* __restrict__ dbg) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n && keys[i] != 0xffffffffu && keys[i] >= key_limit) atomicAdd(&dbg[DBG_SLOT_KEY], 1u);
+  if (i == 0) atomicAdd(&dbg[DBG_CHECKS], 1u);
+}
+
+// test hook of the debug build: swap the keys of two neighbouring entries of different keys (MI355_MSM_DEBUG_CORRUPT=1), so that a
+// test can see the checks FAIL
+__global__ void k_dbg_corrupt(uint2* __restrict__ entries, const uint32_t* __restrict__ totals) {
+  const uint32_t n = totals[0];
+  for (uint32_t i = 0; i + 1 < n; i++)
+    if (entries[i].y != entries[i + 1].y) {
+      const uint32_t k = entries[i].y;
+      entries[i].y = entries[i + 1].y;
+      entries[i + 1].y = k;
+      return;
+    }
+}
+#endif   // MSM_DEBUG
+
+
 #ifndef PART_GEN_GRID
 #define PART_GEN_GRID 512u
 #endif
@@ -830,6 +915,17 @@ inline int part_run(const uint32_t* d_scalars, const uint8_t* d_inf, const PartP
     probe->n = 0;
     (void)hipEventRecord(probe->ev[0], st);
   }
+#ifdef MSM_DEBUG
+  uint32_t* const dbg = b.totals + 4;
+  (void)hipMemsetAsync(dbg, 0, DBG_WORDS * 4, st);
+#define PART_DBG_LEVEL(ENT, SEGS, NSEGS, REM)                                                                              \
+  do {                                                                                                                     \
+    hipLaunchKernelGGL(k_dbg_check_level, dim3((uint32_t)(NSEGS)), dim3(256), 0, st, ENT, SEGS, (uint32_t)(NSEGS), REM, b.totals, dbg); \
+    hipLaunchKernelGGL(k_dbg_check_slots, dim3(1), dim3(256), 0, st, b.totals, 0u, 0u, dbg); /* counts the check */          \
+  } while (0)
+#else
+#define PART_DBG_LEVEL(ENT, SEGS, NSEGS, REM) do { } while (0)
+#endif
   const uint64_t entries = (uint64_t)p.n * p.windows;
   const dim3 scan_grid(part_ceil_div(p.nbins, 256), PART_SCAN_GROUPS);
   const uint32_t l1_grid = 8 * ((p.ntiles + 7) / 8) * p.wgroups;   // l1_tile(): a contiguous tile range per XCD; wgroups blocks per tile
@@ -854,6 +950,7 @@ inline int part_run(const uint32_t* d_scalars, const uint8_t* d_inf, const PartP
   else
     hipLaunchKernelGGL((k_l1_scatter<FR, MONT, false>), dim3(l1_grid), dim3(PART_THREADS), 0, st, d_scalars, d_inf, p, b.matrix, b.entries[0]);
   PART_MARK("l1_scatter");
+  PART_DBG_LEVEL(b.entries[0], b.segs[seg_cur], nsegs, p.lb);
   if (mid) (void)hipEventRecord(mid, st);
   uint32_t rb[4];
   const int np = part_pass_bits(p.lb, rb);
@@ -887,8 +984,22 @@ inline int part_run(const uint32_t* d_scalars, const uint8_t* d_inf, const PartP
       nsegs <<= rb[i];
       seg_cur ^= 1;
       hipLaunchKernelGGL(k_pass_subjobs, dim3(1), dim3(1024), 0, st, b.segs[seg_cur], (uint32_t)nsegs, b.subjob_first, b.totals);
+      PART_DBG_LEVEL(b.entries[cur], b.segs[seg_cur], nsegs, rem);
     }
   }
+#ifdef MSM_DEBUG
+  {
+    const uint32_t key_limit = (p.shared ? 1u : p.windows) * p.half;
+    const uint32_t idx_hi = p.idx0 + p.n + (p.windows - 1) * p.table_stride;
+    if (getenv("MI355_MSM_DEBUG_CORRUPT")) hipLaunchKernelGGL(k_dbg_corrupt, dim3(1), dim3(1), 0, st, b.entries[cur], b.totals);
+    hipLaunchKernelGGL(k_dbg_check_sorted, dim3(2048), dim3(256), 0, st, b.entries[cur], b.totals, key_limit, p.idx0, idx_hi, dbg);
+    if (p.fold)
+      hipLaunchKernelGGL((k_dbg_count_digits<FR, MONT, true>), dim3(part_ceil_div(p.n, 256)), dim3(256), 0, st, d_scalars, d_inf, p, dbg);
+    else
+      hipLaunchKernelGGL((k_dbg_count_digits<FR, MONT, false>), dim3(part_ceil_div(p.n, 256)), dim3(256), 0, st, d_scalars, d_inf, p, dbg);
+    hipLaunchKernelGGL(k_dbg_check_slots, dim3(1), dim3(256), 0, st, b.totals, 0u, 0u, dbg);
+  }
+#endif
   err = hipGetLastError();
   return cur;
 }

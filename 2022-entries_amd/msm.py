@@ -57,6 +57,10 @@ class _RustError(ctypes.Structure):
 
 
 def library_path() -> str:
+    """The product library; MI355_MSM_LIBRARY names another build of it (tests: libmi355msm_debug.so, the -DMSM_DEBUG build)."""
+    override = os.environ.get("MI355_MSM_LIBRARY")
+    if override:
+        return override if os.path.isabs(override) else os.path.join(os.path.dirname(os.path.abspath(__file__)), override)
     return os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmi355msm.so")
 
 

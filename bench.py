@@ -291,13 +291,19 @@ def main():
         # They are NOT measured by this run (counters need their own rocprofv3 pass): `traffic_from` says where the figure was
         # measured, and it is only quoted when that pass ran on the very kernel sources this library was built from.
         traffic, traffic_raw, traffic_from, valu = None, None, None, None
-        pmc_rel = os.path.join("profiles", "r03_pmc_k_accumulate%s.json" % {0: "", 1: "_381", 2: "_g2", 3: "_381g2"}[cid])
+        pmc_rel = os.path.join("profiles", "r04_pmc_k_accumulate%s.json" % {0: "", 1: "_381", 2: "_g2", 3: "_381g2"}[cid])
         pmc_path = os.path.join(ROOT, pmc_rel)
         if (args.npow == (24 if cid >= 2 else 26) and not total_npow and not args.window_bits and not args.lane_entries and not args.precompute
                 and os.path.exists(pmc_path)):
             pmc = json.load(open(pmc_path))
             sha = kernel_source_sha16()
-            if pmc.get("kernel_source_sha16") == sha:
+            # ... and on the same execution plan (window size, entries per lane, lanes, group law: they live in the engine, not in the
+            # hashed kernel sources)
+            plan_now = {"window_bits": tm["window_bits"], "windows": tm["windows"], "lane_entries": tm["lane_entries"], "lanes": tm["lanes"],
+                        "group_law": "extended twisted Edwards (7M mixed add)" if ctx_te_path else "XYZZ (8M+2S mixed add)"}
+            if pmc.get("kernel_source_sha16") == sha and pmc.get("plan") != plan_now:
+                traffic_from = f"not quoted: {pmc_rel} was measured under the plan {pmc.get('plan')}, this run uses {plan_now}"
+            elif pmc.get("kernel_source_sha16") == sha:
                 # corrected = FETCH_SIZE / WRITE_SIZE rescaled by the ratios tools/calib_fetch.hip measured on the kernel's own access
                 # shapes (gfx950 tallies 64 B per fabric request, whether it is a 64- or a 128-byte one)
                 traffic = pmc.get("traffic_bytes_corrected") or pmc["traffic_bytes_raw"]

@@ -267,22 +267,41 @@ pub mod stream_pippenger {
         }
     }
 
-    fn create(buf_size: usize, hashmap: c_int) -> *mut c_void {
+    fn create(buf_size: usize, hashmap: c_int) -> Stream {
         let mut s: *mut c_void = std::ptr::null_mut();
         check(unsafe { sys::mi355_msm_stream_create(&mut s, CURVE, -1, buf_size, hashmap) });
-        s
+        Stream(s)
     }
 
-    fn finalize(stream: *mut c_void) -> G1Projective {
-        let mut out = G1Projective::zero();
-        check(unsafe { sys::mi355_msm_stream_finalize(stream, &mut out as *mut _ as *mut c_void) });
-        check(unsafe { sys::mi355_msm_stream_destroy(stream) });
-        out
+    /// The native stream object, freed exactly once: by `finalize` or, for an accumulator that is dropped without one (or unwinds out
+    /// of a failed `add`), by `Drop` -- the arkworks types are plain Rust values that free themselves, and so are these.
+    struct Stream(*mut c_void);
+
+    impl Stream {
+        fn finalize(mut self) -> G1Projective {
+            let mut out = G1Projective::zero();
+            let err = unsafe { sys::mi355_msm_stream_finalize(self.0, &mut out as *mut _ as *mut c_void) };
+            let raw = std::mem::replace(&mut self.0, std::ptr::null_mut());   // Drop below sees null: no double free
+            let derr = unsafe { sys::mi355_msm_stream_destroy(raw) };
+            check(err);
+            check(derr);
+            out
+        }
+    }
+
+    impl Drop for Stream {
+        fn drop(&mut self) {
+            if !self.0.is_null() {
+                // (the error, if any, is dropped with its message: Drop must not panic)
+                let _ = unsafe { sys::mi355_msm_stream_destroy(self.0) };
+                self.0 = std::ptr::null_mut();
+            }
+        }
     }
 
     /// Struct for the chunked Pippenger algorithm.
     pub struct ChunkedPippenger {
-        stream: *mut c_void,
+        stream: Stream,
     }
 
     impl ChunkedPippenger {
@@ -304,7 +323,7 @@ pub mod stream_pippenger {
         {
             check(unsafe {
                 sys::mi355_msm_stream_add(
-                    self.stream,
+                    self.stream.0,
                     base.borrow() as *const G1Affine as *const c_void,
                     std::mem::size_of::<G1Affine>(),
                     scalar.borrow() as *const _ as *const c_void,
@@ -317,19 +336,19 @@ pub mod stream_pippenger {
         pub fn add_slice(&mut self, bases: &[G1Affine], scalars: &[<Fr as PrimeField>::BigInt]) {
             let n = bases.len().min(scalars.len());
             check(unsafe {
-                sys::mi355_msm_stream_add(self.stream, bases.as_ptr() as *const c_void, std::mem::size_of::<G1Affine>(), scalars.as_ptr() as *const c_void, n)
+                sys::mi355_msm_stream_add(self.stream.0, bases.as_ptr() as *const c_void, std::mem::size_of::<G1Affine>(), scalars.as_ptr() as *const c_void, n)
             });
         }
 
         /// Output the final Pippenger algorithm result.
         pub fn finalize(self) -> G1Projective {
-            finalize(self.stream)
+            self.stream.finalize()
         }
     }
 
     /// Hash map struct for Pippenger algorithm.
     pub struct HashMapPippenger {
-        stream: *mut c_void,
+        stream: Stream,
     }
 
     impl HashMapPippenger {
@@ -337,7 +356,7 @@ pub mod stream_pippenger {
         pub fn new(max_msm_buffer: usize) -> Self {
             let stream = create(max_msm_buffer, 1);
             // the scalars of this accumulator are `Fr` values (Montgomery images): the device converts at the flush
-            check(unsafe { sys::mi355_msm_stream_set_option(stream, b"scalars_montgomery\0".as_ptr() as *const c_char, 1) });
+            check(unsafe { sys::mi355_msm_stream_set_option(stream.0, b"scalars_montgomery\0".as_ptr() as *const c_char, 1) });
             Self { stream }
         }
 
@@ -349,7 +368,7 @@ pub mod stream_pippenger {
         {
             check(unsafe {
                 sys::mi355_msm_stream_add(
-                    self.stream,
+                    self.stream.0,
                     base.borrow() as *const G1Affine as *const c_void,
                     std::mem::size_of::<G1Affine>(),
                     scalar.borrow() as *const Fr as *const c_void,
@@ -360,7 +379,7 @@ pub mod stream_pippenger {
 
         /// Update the final result with (base, scalar) pairs in the hash map.
         pub fn finalize(self) -> G1Projective {
-            finalize(self.stream)
+            self.stream.finalize()
         }
     }
 }

@@ -239,10 +239,9 @@ def test_idle_context_gives_its_buffers_back_above_the_threshold(ea, oracle):
 
 
 def test_out_of_memory_reclaims_the_idle_contexts_first(ea, oracle):
-    """An allocation that does not fit frees the parked stateless contexts and retries before anything fails or shrinks
-    (DevBuf::reserve -> reclaim_idle_device_memory): park a context, then ask a NEW context for almost all of the device."""
-    import torch
-
+    """A run whose allocation fails with out-of-memory first frees the parked stateless contexts and tries the SAME chunk again;
+    only when nothing is parked does it fall back to half the chunk (the inject_alloc_failures hook makes the failure
+    deterministic; DevBuf::reserve applies the same rule to a real hipMalloc failure)."""
     n = 1 << 16
     bases = ea.generate_points(n, distinct=4096, seed=5)
     sc = _scalars(n, 6)
@@ -250,18 +249,15 @@ def test_out_of_memory_reclaims_the_idle_contexts_first(ea, oracle):
     ea.trim()
     assert ea.msm(bases, sc) == exp
     assert ea.pool_stats()["idle_contexts"] == 1
-    free_b, _total = torch.cuda.mem_get_info()
-    hog = torch.empty(max(1, free_b - (16 << 20)), dtype=torch.uint8, device="cuda")    # leave 16 MiB: less than the context below needs
-    try:
-        ctx = ea.multi_scalar_mult_init(bases, "bls12_377_g1")
-        assert ctx.run(sc)[0] == exp
-        backoffs = ctx.query("oom_backoffs")
-        ctx.close()
-    finally:
-        del hog
-        torch.cuda.empty_cache()
+    ctx = ea.multi_scalar_mult_init(bases, "bls12_377_g1")
+    ctx.set_option("inject_alloc_failures", 1)
+    assert ctx.run(sc)[0] == exp
     assert ea.pool_stats()["idle_contexts"] == 0, "the parked context should have been reclaimed by the failing allocation"
-    assert backoffs >= 0
+    assert ctx.query("oom_backoffs") == 0 and ctx.query("chunk_cap") == 0          # ... and the chunk was NOT halved
+    ctx.set_option("inject_alloc_failures", 1)                                      # nothing parked any more: now the chunk halves
+    assert ctx.run(sc)[0] == exp
+    assert ctx.query("oom_backoffs") == 1
+    ctx.close()
 
 
 def test_concurrent_streaming_accumulators(ea, oracle):

@@ -23,11 +23,12 @@ sys.path.insert(0, ROOT)
 from bench import kernel_source_sha16  # noqa: E402
 
 prof, out_json, curve = sys.argv[1], sys.argv[2], sys.argv[3]
-calib_path = sys.argv[4] if len(sys.argv) > 4 else os.path.join(ROOT, "profiles", "r03_calib_fetch.txt")
+calib_path = sys.argv[4] if len(sys.argv) > 4 else os.path.join(ROOT, "profiles", "r03_calib_fetch.txt")   # (the TRACKED copy)
 CFG = {
     "377": dict(npow=26, c=20, windows=13, record=192, law="twisted Edwards (7M)", gather="calib_gather_glds<3>", entry="calib_gather_lane<1>", entries_per_refill=8),
     "381": dict(npow=26, c=20, windows=13, record=128, law="XYZZ (8M + 2S)", gather="calib_gather_glds<2>", entry="calib_gather_lane<1>", entries_per_refill=4),
     "g2": dict(npow=24, c=20, windows=13, record=256, law="XYZZ over Fq2", gather="calib_gather_glds<4>", entry=None, entries_per_refill=1),
+    "381g2": dict(npow=24, c=20, windows=13, record=256, law="XYZZ over Fq2 (BLS12-381)", gather="calib_gather_glds<4>", entry=None, entries_per_refill=1),
 }[curve]
 calib = {}
 if os.path.exists(calib_path):
@@ -73,7 +74,7 @@ entry_bytes = entries * 8.0
 r_gather = calib.get(CFG["gather"], {}).get("fetch_ratio")
 r_entry = calib.get(CFG["entry"], {}).get("fetch_ratio") if CFG["entry"] else None
 model = {"base_record_bytes": CFG["record"], "bases_bytes": base_bytes, "entries_bytes": entry_bytes,
-         "algorithmic_bytes_per_pair_SURVEY_8d": 224 if curve == "g2" else 128,
+         "algorithmic_bytes_per_pair_SURVEY_8d": 224 if curve in ("g2", "381g2") else 128,
          "structural_bytes_per_pair": (base_bytes + entry_bytes) / n,
          "calibration": {"file": os.path.relpath(calib_path, ROOT), "gather_ratio": r_gather, "entry_ratio": r_entry}}
 corrected = None
@@ -90,9 +91,20 @@ if r_gather:
         model["entry_sector_requests"] = sector_requests
         model["entry_sectors_per_entry"] = sector_requests / entries
         corrected = base_bytes + sector_requests * 64.0
+# the execution plan the counters belong to (window size, entries per lane, lanes, group law live in msm_engine.hip's Plan, which the
+# kernel-source hash does not cover -- ADVICE r3): taken from the bench line of the kernel-trace pass, compared by bench.py
+plan = None
+sb = os.path.join(prof, "stats_bench.json")
+if os.path.exists(sb):
+    lines = [ln for ln in open(sb).read().splitlines() if ln.startswith("{")]
+    if lines:
+        cfgj = json.loads(lines[-1])["config"]
+        plan = {"window_bits": cfgj["window_bits"], "windows": cfgj["windows"], "lane_entries": cfgj["lane_entries"], "group_law": cfgj["group_law"],
+                "lanes": c.get("lanes")}
 res = {
+    "plan": plan,
     "config": "bls12_%s npow=%d (c = %d, %d windows), the k_accumulate_glds launch of a bench step: %s, LDS-DMA quad-cooperative gathers of %d-B "
-              "records, sorted (value, key) entries %s" % ({"377": "377_g1", "381": "381_g1", "g2": "377_g2"}[curve], CFG["npow"], CFG["c"], CFG["windows"], CFG["law"],
+              "records, sorted (value, key) entries %s" % ({"377": "377_g1", "381": "381_g1", "g2": "377_g2", "381g2": "381_g2"}[curve], CFG["npow"], CFG["c"], CFG["windows"], CFG["law"],
                                                            CFG["record"], "through a register queue (%d per refill)" % CFG["entries_per_refill"] if CFG["entry"] else "one per load"),
     "source": "tools/profile_gpu.sh: rocprofv3 --kernel-trace --pmc ..., one counter group per pass",
     "kernel_source_sha16": kernel_source_sha16(),
