@@ -82,6 +82,7 @@ def test_carried_tables_and_fold(ea, oracle):
 
 def test_allocation_failure_in_the_middle_of_a_carried_batch(ea, oracle):
     """The totals of the chunks already merged survive the back-off (release_work_buffers keeps carry_buckets)."""
+    ea.trim()        # nothing parked: the failure below must take the back-off path, not the reclaim-and-retry one
     n = 40000
     bases = ea.generate_points(n, distinct=500, seed=2)
     sc = _scalars(0, n, 6)

@@ -24,6 +24,7 @@ import entries_amd as ea
 lib = ea.load_library()
 assert b"+debug-invariants" in lib.mi355_msm_version(), lib.mi355_msm_version()
 oracle = ctypes.CDLL(os.path.join(os.environ["REPO"], "oracle", "liboracle.so"))
+oracle.oracle_msm.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_int]
 out = {}
 for curve, cid, npow in (("bls12_377_g1", 0, 20), ("bls12_381_g1", 1, 20), ("bls12_377_g2", 2, 18), ("bls12_381_g2", 3, 16)):
     n = 1 << npow
@@ -45,11 +46,11 @@ for curve, cid, npow in (("bls12_377_g1", 0, 20), ("bls12_381_g1", 1, 20), ("bls
         got = ctx.run(sc)[0]
         checks = ctx.query("debug_checks")
         ctx.close()
-        assert checks >= 4, (curve, opts, checks)
+        assert checks >= 3, (curve, opts, checks)     # level 1, the sorted output + digit count, the slot keys: per chunk
         results[json.dumps(opts)] = [got.hex(), checks]
     small = 1 << 13     # a prefix the oracle finishes quickly: the debug build's results are the product's results
     exp = ctypes.create_string_buffer(ea.projective_bytes(curve))
-    assert oracle.oracle_msm(cid, bases.ctypes.data, ctypes.c_size_t(ea.affine_stride(curve)), sc.ctypes.data, ctypes.c_size_t(small), exp, 0) == 0
+    assert oracle.oracle_msm(cid, bases.ctypes.data, ea.affine_stride(curve), sc.ctypes.data, small, exp, 0) == 0
     assert ea.msm(bases[:small], sc[:small], curve) == exp.raw, curve
     assert len({v[0] for v in results.values()}) == 1, (curve, "options changed the result")
     out[curve] = {k: v[1] for k, v in results.items()}

@@ -42,6 +42,7 @@ def test_chunks_shrink_to_the_memory_budget(ea, oracle, curve, cid):
 
 
 def test_allocation_failure_halves_the_chunk_and_retries(ea, oracle):
+    ea.trim()        # (a parked stateless context would be reclaimed first and the same chunk retried: tests/test_gpu_stateless.py)
     n = 60000
     bases = ea.generate_points(n, distinct=777, seed=9)
     sc = _scalars(2 * n, 4)
@@ -60,6 +61,7 @@ def test_allocation_failure_halves_the_chunk_and_retries(ea, oracle):
 def test_allocation_failure_backoff_in_every_shard_of_a_sharded_context(ea, oracle):
     """The injection counter is a field of each shard's context (it used to be a thread-local of the CALLING thread, which the
     shards' worker threads never saw)."""
+    ea.trim()
     n = 50000
     bases = ea.generate_points(n, distinct=333, seed=10)
     sc = _scalars(n, 5)
