@@ -86,10 +86,8 @@ def build_engine(force: bool = False) -> str:
     return out
 
 
-def build_debug_engine(force: bool = False) -> str:
-    """libmi355msm_debug.so (tests only): the host orchestration and the grouping unit compiled with -DMSM_DEBUG -- invariant checks
-    after every grouping level and after the accumulation (csrc/partition.hpp; the reference keeps such a self-check, disabled, in
-    CMB Partition4096.cu:419-432) -- linked with the SAME kernel objects as the product.  tests/test_gpu_debug_build.py runs it."""
+def _debug_engine_compile(force: bool = False):
+    """Start the -DMSM_DEBUG compiles of the two units that differ from the product; returns (jobs, objs, out)."""
     out = os.path.join(PKG, "libmi355msm_debug.so")
     objdir = os.path.join(PKG, "build", "debug")
     os.makedirs(objdir, exist_ok=True)
@@ -111,12 +109,23 @@ def build_debug_engine(force: bool = False) -> str:
             cmd = [cc, "--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-DMSM_DEBUG", "-MD", "-MF", dfile, "-c", src, "-o", obj]
             print("+", " ".join(cmd), flush=True)
             jobs.append((unit, subprocess.Popen(cmd)))
+    return jobs, objs, out
+
+
+def _debug_engine_link(jobs, objs, out, force: bool = False) -> str:
     failed = [unit for unit, pr in jobs if pr.wait() != 0]
     if failed:
         raise RuntimeError("hipcc failed for (debug) " + ", ".join(failed))
     if force or jobs or _newer(out, objs):
-        _run([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)
+        _run([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)
     return out
+
+
+def build_debug_engine(force: bool = False) -> str:
+    """libmi355msm_debug.so (tests only): the host orchestration and the grouping unit compiled with -DMSM_DEBUG -- invariant checks
+    after every grouping level and after the accumulation (csrc/partition.hpp; the reference keeps such a self-check, disabled, in
+    CMB Partition4096.cu:419-432) -- linked with the SAME kernel objects as the product.  tests/test_gpu_debug_build.py runs it."""
+    return _debug_engine_link(*_debug_engine_compile(force), force)
 
 
 def build_hosttest(force: bool = False) -> str:
@@ -160,8 +169,9 @@ def build_oracle() -> str:
 
 
 def build_all(force: bool = False) -> None:
+    dbg = _debug_engine_compile(force)   # (its two units compile while the product's do; it links the product's kernel objects)
     build_engine(force)
-    build_debug_engine(force)
+    _debug_engine_link(*dbg, force)
     build_hosttest(force)
     build_devtest(force)
     build_shims(force)

@@ -148,7 +148,9 @@ inline uint32_t ilog2_floor(uint64_t v) { uint32_t r = 0; while (v >>= 1) r++; r
 // top window is only partly populated: with `rem` significant bits left it behaves like a full window, with none it
 // only ever receives the signed-digit carry (about half of the scalars).  Buckets exist for all ceil(257/c) windows (any 256-bit
 // scalar is legal), or for ONE window when precomputed tables let all digits share a bucket set.
-int choose_window_bits(size_t n, int scalar_bits, bool shared_buckets, bool fold = false) {
+// `levels` = precomputed table levels k (0: none; >= windows: one bucket set for all): windows g, g + G, ... share bucket set g,
+// G = ceil(windows / k) sets exist.
+int choose_window_bits(size_t n, int scalar_bits, bool shared_buckets, bool fold = false, int levels = 0) {
   // Between 2^12 and 2^19 pairs an MSM is latency, not throughput: what a window size costs is the launches it implies
   // (two scan steps of the bucket reduction per bit, a grouping pass more from 12 bits on, per-window steps of the level-1
   // tiles) and the model below does not see them.  Measured on all three curves (tools/small_c_sweep.py,
@@ -168,8 +170,11 @@ int choose_window_bits(size_t n, int scalar_bits, bool shared_buckets, bool fold
     const int bits = (fold && n >= ((size_t)1 << 25)) ? scalar_bits - 1 : scalar_bits;
     const int full = bits / c, rem = bits - full * c;
     const double eff = full + (rem >= 2 ? 1.0 : (bits != scalar_bits && rem == 0 ? (scalar_bits == 253 ? 0.145 : 0.448) : 0.55));
-    const double alloc = shared_buckets ? 1.0 : (double)((257 + c - 1) / c);
-    const double cost = eff * (double)n * 10.0 + alloc * (double)(1ull << (c - 1)) * 50.0;
+    const int wins = (257 + c - 1) / c;
+    const double alloc = shared_buckets ? (double)(levels > 0 ? (wins + std::min(levels, wins) - 1) / std::min(levels, wins) : 1) : (double)wins;
+    // from 22 bits on the grouping needs a second generic pass (level 1 resolves 10 bucket bits, a pass 10 more): ~ 0.6 additions' worth per entry
+    const double group = c >= 22 ? 0.6 : 0.0;
+    const double cost = (eff + group * wins) * (double)n * 10.0 + alloc * (double)(1ull << (c - 1)) * 50.0;
     if (cost < best_cost) { best_cost = cost; best = c; }
   }
   return best;
@@ -177,7 +182,8 @@ int choose_window_bits(size_t n, int scalar_bits, bool shared_buckets, bool fold
 
 struct Plan {
   uint32_t c, windows, half, keybits;
-  uint32_t bucket_windows;  // windows that own buckets: `windows`, or 1 with precomputed tables
+  uint32_t bucket_windows;  // windows that own buckets: `windows`; with precomputed tables the bucket sets G = ceil(windows / levels)
+  uint32_t levels;          // table levels in use (1 = none)
   uint64_t entries;     // windows * n
   uint32_t K, nlanes;   // accumulate geometry
   uint32_t segK;        // fragment-merge fan-in
@@ -213,6 +219,7 @@ struct mi355_msm_ctx {
   hipEvent_t ev[8] = {};
   long opt_window_bits = 0, opt_lane_entries = 0, opt_max_chunk = 0, opt_seg_entries = 0, opt_scalars_montgomery = 0, opt_reduce_scan_log = 0;
   long opt_precompute = 0;
+  long opt_table_levels = 0;      // with precompute: table levels k (0 = one per window); windows g, g + G, ... share bucket set g
   long opt_assume_subgroup = 0;   // 1: every base is in the order-r subgroup (r P = O), so a scalar k in (r/2, r) may run as (r - k)(-P)
   long opt_reduce_log_chunk = 0, opt_reduce_log_chunk0 = 0;
   long opt_reduce_scan = -1;      // 0: recursive chunked running sums only; otherwise the scan tail (default)
@@ -261,7 +268,9 @@ struct mi355_msm_ctx {
     else
       p.c = (opt_window_bits && !pre_c) ? (uint32_t)opt_window_bits : (uint32_t)choose_window_bits(n, scalar_bits(), false, opt_assume_subgroup != 0);
     p.windows = (257 + p.c - 1) / p.c;
-    p.bucket_windows = tables ? 1 : p.windows;
+    p.levels = tables ? std::min<uint32_t>(pre_windows, p.windows) : 1;
+    p.bucket_windows = ceil_div(p.windows, p.levels);
+    p.levels = ceil_div(p.windows, p.bucket_windows);
     p.half = 1u << (p.c - 1);
     p.keybits = ilog2_floor(p.bucket_windows * p.half) + 1;   // bits of a bucket key (reported by mi355_msm_plan)
     p.entries = (uint64_t)p.windows * n;
@@ -355,7 +364,7 @@ hipStream_t create_copy_stream() {
 
 // Device bytes of the per-run work buffers of one chunk (keys/vals x2, buckets, slots x2, reduce x4); `el` = 2 for Fq2 points.
 uint64_t work_bytes(const Plan& p, uint64_t el, bool carry = false) {
-  const PartPlan pp = part_plan((uint32_t)(p.entries / p.windows), p.c, p.windows, p.bucket_windows == 1 && p.windows > 1, 0, 0);
+  const PartPlan pp = part_plan((uint32_t)(p.entries / p.windows), p.c, p.windows, p.levels, 0, 0);
   const PartScratchSizes ps = part_scratch_sizes(pp);
   return p.entries * 16 + ps.matrix + ps.partial + ps.segs_a + ps.segs_b + ps.subjob_first + ps.counts + ps.totals +
          (uint64_t)p.bucket_windows * p.half * 224 * el * (carry ? 2 : 1) + 2 * (2ull * p.nlanes) * (224 * el + 4) + (p.scan_direct ? (uint64_t)p.bucket_windows * p.half : 4ull * p.bucket_windows * p.scan_nb) * 224 * el;
@@ -383,7 +392,7 @@ struct WorkBytes {
 
 WorkBytes chunk_work_bytes(const Plan& p, size_t n, bool use_tables, size_t xyzz, bool carry = false) {
   WorkBytes w;
-  const PartPlan gp = part_plan((uint32_t)n, p.c, p.windows, use_tables, 0, 0);
+  const PartPlan gp = part_plan((uint32_t)n, p.c, p.windows, use_tables ? p.levels : 1, 0, 0);
   const PartScratchSizes gs = part_scratch_sizes(gp);
   const size_t nbuckets = (size_t)p.bucket_windows * p.half, nslots0 = 2 * (size_t)p.nlanes;
   const size_t red0 = p.scan_direct ? nbuckets : (size_t)p.bucket_windows * p.scan_nb;   // direct scan: a second bucket-sized array to ping-pong with
@@ -475,15 +484,22 @@ void convert_bases(mi355_msm_ctx* ctx, const uint8_t* d_raw, size_t n, size_t st
   HIP_OK(Launch<E>::convert_bases(d_raw, stride, (uint32_t)n, ctx->bases_serialized, ctx->bases.as<AD>(), ctx->inf.as<uint8_t>(), st));
 }
 
-// Build the tables 2^(c w) * P_i, w = 1 .. windows-1, behind the converted bases (level 0).
+// Build the table levels behind the converted bases (level 0): level j holds 2^(c G j) * P_i, j = 1 .. k-1, where G = ceil(windows / k)
+// is the number of bucket sets (k = windows, G = 1: a level per window, the round-1..3 form; CMB PrecomputePoints.cu:10-39 builds
+// k = 6 levels 2^(46 j) P for its 23-bit windows, i.e. G = 2).
 template <class C>
 void build_tables(mi355_msm_ctx* ctx, const uint8_t* d_raw, size_t n, size_t stride, hipStream_t st) {
   using E = typename C::E;
   using El = typename E::T;
   using AD = AffineDevT<El>;
   using XD = XyzzDevT<El>;
-  const uint32_t c = ctx->opt_window_bits ? (uint32_t)ctx->opt_window_bits : (uint32_t)choose_window_bits(n, C::SCALAR_BITS, true);
-  const uint32_t windows = (257 + c - 1) / c;
+  const int want_levels = (int)ctx->opt_table_levels;
+  const uint32_t c = ctx->opt_window_bits ? (uint32_t)ctx->opt_window_bits : (uint32_t)choose_window_bits(n, C::SCALAR_BITS, true, false, want_levels);
+  const uint32_t all_windows = (257 + c - 1) / c;
+  uint32_t windows = want_levels > 0 ? std::min<uint32_t>((uint32_t)want_levels, all_windows) : all_windows;   // = table levels from here on
+  const uint32_t bsets = ceil_div(all_windows, windows);
+  windows = ceil_div(all_windows, bsets);
+  const uint32_t level_shift = c * bsets;   // doublings between two levels
   if ((uint64_t)windows * n >= (1ull << 31)) bad_arg("precompute: %u tables of %zu points exceed the 2^31 index range", windows, n);
   const size_t table_bytes = (size_t)windows * n * sizeof(AD);
   size_t free_b = 0, total_b = 0;
@@ -503,7 +519,7 @@ void build_tables(mi355_msm_ctx* ctx, const uint8_t* d_raw, size_t n, size_t str
       AD* next = ctx->bases.as<AD>() + (size_t)w * n;
       uint8_t* inf_prev = ctx->inf.as<uint8_t>() + (size_t)(w - 1) * n;
       uint8_t* inf_next = ctx->inf.as<uint8_t>() + (size_t)w * n;
-      HIP_OK(Launch<E>::pre_double(prev, inf_prev, (uint32_t)n, c, xyzz.as<XD>(), st));
+      HIP_OK(Launch<E>::pre_double(prev, inf_prev, (uint32_t)n, level_shift, xyzz.as<XD>(), st));
       HIP_OK(Launch<E>::pre_normalize(xyzz.as<XD>(), (uint32_t)n, J, prefix.as<El>(), next, inf_next, st));
     }
     HIP_OK(hipStreamSynchronize(st));
@@ -686,7 +702,7 @@ bool run_chunk_impl(mi355_msm_ctx* ctx, const uint32_t* d_scalars, size_t base0,
   }
   reserve_work(ctx, chunk_work_bytes(p, n, use_tables, sizeof(XyzzDev), carry != nullptr));
   const uint32_t table_stride = use_tables ? (uint32_t)ctx->nbases : 0u;
-  const PartPlan gp = part_plan((uint32_t)n, p.c, p.windows, use_tables, (uint32_t)base0, table_stride, ctx->opt_assume_subgroup != 0);
+  const PartPlan gp = part_plan((uint32_t)n, p.c, p.windows, use_tables ? p.levels : 1, (uint32_t)base0, table_stride, ctx->opt_assume_subgroup != 0);
   const size_t nbuckets = (size_t)p.bucket_windows * p.half;
   if (ctx->pinned_bytes < p.windows * sizeof(XyzzDev)) {
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
@@ -1391,6 +1407,12 @@ RustError mi355_msm_set_option(mi355_msm_ctx* ctx, const char* key, long value) 
       ctx->opt_twisted_edwards = value != 0;   // takes effect at the next set_bases
     } else if (k == "precompute") {
       ctx->opt_precompute = value != 0;   // takes effect at the next set_bases
+    } else if (k == "table_levels") {
+      // with "precompute": how many table levels to build (0 = one per window, every window then shares ONE bucket set).  With k levels
+      // the windows g, g + G, g + 2G, ... share bucket set g (G = ceil(windows / k)): k times the base memory instead of `windows` times
+      // -- yrrid's shape is k = 6, two bucket sets (CMB PrecomputePoints.cu:10-39, MSM.cu:380-383).  Takes effect at the next set_bases.
+      if (value < 0 || value > 64) bad_arg("table_levels %ld out of range [0, 64]", value);
+      ctx->opt_table_levels = value;
     } else if (k == "scalars_montgomery") {
       ctx->opt_scalars_montgomery = value != 0;
     } else if (k == "assume_subgroup") {
@@ -1572,8 +1594,8 @@ RustError mi355_msm_last_stateless(double* out, size_t count) {
   return guarded([&] {
     if (!out) bad_arg("null output");
     const StatelessStats& s = g_last_stateless;
-    const double v[8] = {s.total_ms, s.setup_ms, s.wait_upload_ms, s.compute_ms, s.tail_ms, s.slices, s.threads, s.bytes};
-    for (size_t i = 0; i < count && i < 8; i++) out[i] = v[i];
+    const double v[10] = {s.total_ms, s.setup_ms, s.wait_upload_ms, s.compute_ms, s.tail_ms, s.slices, s.threads, s.bytes, s.dma_done_ms, s.first_dma_ms};
+    for (size_t i = 0; i < count && i < 10; i++) out[i] = v[i];
   });
 }
 
@@ -1636,8 +1658,10 @@ RustError mi355_msm_plan(int curve, size_t npoints, int precompute, const long* 
     }
     if (tmp.opt_window_bits && (tmp.opt_window_bits < 2 || tmp.opt_window_bits > 24)) bad_arg("window_bits out of range");
     if (tmp.opt_seg_entries && tmp.opt_seg_entries < 4) bad_arg("seg_entries out of range");
-    if (precompute)
+    if (precompute) {
       tmp.pre_c = tmp.opt_window_bits ? (uint32_t)tmp.opt_window_bits : (uint32_t)choose_window_bits(npoints, tmp.scalar_bits(), true);
+      tmp.pre_windows = (257 + tmp.pre_c - 1) / tmp.pre_c;   // a table level per window
+    }
     const Plan p = tmp.plan(npoints);
     // fragment-merge levels: n slots -> 2*ceil(n/segK) until one lane is left
     uint64_t merge_levels = 0;

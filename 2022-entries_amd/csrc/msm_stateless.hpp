@@ -160,6 +160,8 @@ bool reclaim_idle_device_memory() {
 struct StatelessStats {
   double total_ms = 0, setup_ms = 0, wait_upload_ms = 0, compute_ms = 0, tail_ms = 0;
   double slices = 0, threads = 0, bytes = 0;
+  double dma_done_ms = 0;       // when the LAST DMA of the call completed, from the start of the call (device clock of the copy stream)
+  double first_dma_ms = 0;      // when the copy stream started
 };
 thread_local StatelessStats g_last_stateless;
 
@@ -282,13 +284,13 @@ void stateless_t(mi355_msm_ctx* ctx, uint8_t* out, const uint8_t* affine, size_t
       up.slice_ev.assign(S, nullptr);
       up.conv_ev.assign(S, nullptr);
       for (uint32_t s = 0; s < S; s++) {
-        HIP_OK(hipEventCreateWithFlags(&up.slice_ev[s], trace ? hipEventDefault : hipEventDisableTiming));
+        // (the last slice's event is always a timing one: "when were the uploads done" is part of the call's report)
+        HIP_OK(hipEventCreateWithFlags(&up.slice_ev[s], (trace || s + 1 == S) ? hipEventDefault : hipEventDisableTiming));
         HIP_OK(hipEventCreateWithFlags(&up.conv_ev[s], trace ? hipEventDefault : hipEventDisableTiming));
       }
-      if (trace) {
-        HIP_OK(hipEventCreate(&tr_t0));
-        HIP_OK(hipEventRecord(tr_t0, up.copy_stream));
-      }
+      HIP_OK(hipEventCreate(&tr_t0));
+      HIP_OK(hipEventRecord(tr_t0, up.copy_stream));
+      stats.first_dma_ms = ms_since(t_begin);
       tr_setup.emplace_back("stream + events", ms_since(t_begin));
       up.prepare(S);
       // pieces in upload order: the scalars of a slice first (its grouping needs them before the accumulation needs bases)
@@ -367,9 +369,16 @@ void stateless_t(mi355_msm_ctx* ctx, uint8_t* out, const uint8_t* affine, size_t
           fprintf(stderr, "  slice %2u  pairs %9zu  all DMAs enqueued @%7.1f (host)  DMA done +%7.1f  converted +%7.1f (device, from the copy stream's start)  chunk folded @%7.1f (host)\n",
                   s, lo[s + 1] - lo[s], tr_ready[s], dma, conv, tr_done[s]);
         }
+      }
+      {
+        float dma = 0;
+        if (hipEventElapsedTime(&dma, tr_t0, up.slice_ev[S - 1]) == hipSuccess) stats.dma_done_ms = stats.first_dma_ms + dma;
+        (void)hipGetLastError();
         (void)hipEventDestroy(tr_t0);
+        tr_t0 = nullptr;
       }
     } catch (...) {
+      if (tr_t0) (void)hipEventDestroy(tr_t0);
       up.abort_and_join();
       (void)hipStreamSynchronize(st);
       if (up.copy_stream) (void)hipStreamSynchronize(up.copy_stream);

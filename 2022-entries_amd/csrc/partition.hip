@@ -19,7 +19,7 @@ hipError_t PartLaunch::debug_finish(const PartPlan& p, const PartBuffers& b, con
   if (what && what_len) what[0] = 0;
 #ifdef MSM_DEBUG
   uint32_t* const dbg = b.totals + 4;
-  const uint32_t key_limit = (p.shared ? 1u : p.windows) * p.half;
+  const uint32_t key_limit = p.bsets * p.half;
   hipLaunchKernelGGL(k_dbg_check_slots, dim3(part_ceil_div(nslots ? nslots : 1, 256)), dim3(256), 0, st, slot_keys, nslots, key_limit, dbg);
   hipError_t e = hipStreamSynchronize(st);
   if (e != hipSuccess) return e;

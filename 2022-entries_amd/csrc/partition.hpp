@@ -211,11 +211,29 @@ __device__ __forceinline__ void few_bins_count(uint32_t* cnt, uint32_t b1, uint3
   }
 }
 
-// Level-1 bin of (window w, bucket b): window-major normally; bucket-major with shared buckets, so that the W runs of one
+// Level-1 bin of (window w, top bucket bits hi): window-major normally.  With table levels the windows g, g + G, ... share bucket set
+// g: their bins are NEIGHBOURS ((g b1 + hi) levels + j for level j = w / G), so that the runs of one bucket range form ONE segment
+// for the next pass (k_l1_merge_shared).
+__device__ __forceinline__ uint32_t l1_bin_of(const PartPlan& p, uint32_t w, uint32_t hi) {
+  if (!p.shared) return w * p.b1 + hi;
+  const uint32_t j = w / p.bsets, g = w - j * p.bsets;
+  return (g * p.b1 + hi) * p.levels + j;
+}
+// the window a level-1 bin belongs to (>= windows for the unused bins of the last table level)
+__device__ __forceinline__ uint32_t l1_window_of_bin(const PartPlan& p, uint32_t b) {
+  if (!p.shared) return b / p.b1;
+  const uint32_t q = b / p.levels, j = b - q * p.levels;
+  return q / p.b1 + p.bsets * j;
+}
+// base index of scalar i in window w: table level w / bsets lies (w / bsets) * table_stride further on
+__device__ __forceinline__ uint32_t l1_base_index(const PartPlan& p, uint32_t i, uint32_t w) {
+  return p.idx0 + i + (p.table_stride ? (w / p.bsets) * p.table_stride : 0u);
+}
+// (bucket b): window-major normally; bucket-major with shared buckets, so that the W runs of one
 // bucket range are neighbours and form ONE segment for the next pass.
 __device__ __forceinline__ uint32_t l1_bin(const PartPlan& p, uint32_t w, uint32_t bucket) {
   const uint32_t hi = bucket >> p.lb;
-  return p.shared ? hi * p.windows + w : w * p.b1 + hi;
+  return l1_bin_of(p, w, hi);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
@@ -255,7 +273,7 @@ __global__ void __launch_bounds__(PART_THREADS) k_l1_hist(const uint32_t* __rest
       next_digit<FOLD>(st, scalar_window(st.s, w * p.c) & wmask, p.c, p.half, wmask, flip, FOLD ? fr_window<FR>(w, p.c, wmask) : 0u, mag, neg);
       if (w < w_lo || w >= w_hi) continue;   // (block-uniform) another block of this tile counts that window
       bool dead = dead0;
-      if (have && p.table_stride) dead = inf[p.idx0 + i + w * p.table_stride] != 0;
+      if (have && p.table_stride) dead = inf[l1_base_index(p, i, w)] != 0;
       const bool ok = mag != 0 && !dead;
       if (few) {
         // every lane of the wave takes part in the ballots (lanes past the end contribute nothing)
@@ -263,7 +281,7 @@ __global__ void __launch_bounds__(PART_THREADS) k_l1_hist(const uint32_t* __rest
         if (p.shared) {
           for (uint32_t v = 0; v < p.b1; v++) {
             const uint64_t m = __builtin_amdgcn_ballot_w64(ok && hi == v);
-            if (m && (threadIdx.x & 63) == (uint32_t)(__ffsll((unsigned long long)m) - 1)) atomicAdd(&hist[v * p.windows + w], (uint32_t)__popcll(m));
+            if (m && (threadIdx.x & 63) == (uint32_t)(__ffsll((unsigned long long)m) - 1)) atomicAdd(&hist[l1_bin_of(p, w, v)], (uint32_t)__popcll(m));
           }
         } else {
           few_bins_count(hist, p.b1, w * p.b1, ok, hi);
@@ -281,8 +299,8 @@ __global__ void __launch_bounds__(PART_THREADS) k_l1_hist(const uint32_t* __rest
   // the row of a tile is written by its blocks together: each the bins of its own windows
   uint32_t* row = matrix + (size_t)tile * p.nbins;
   for (uint32_t b = threadIdx.x; b < p.nbins; b += PART_THREADS) {
-    const uint32_t w = p.shared ? b % p.windows : b / p.b1;
-    if (w >= w_lo && w < w_hi) row[b] = hist[b];
+    const uint32_t w = l1_window_of_bin(p, b);
+    if ((w >= w_lo && w < w_hi) || (w >= p.windows && w_hi == p.windows)) row[b] = hist[b];   // (unused bins: zero, written by the last group)
   }
 }
 
@@ -335,7 +353,7 @@ __global__ void __launch_bounds__(1024) k_l1_scan_b(uint32_t* __restrict__ parti
       // key bits resolved so far: window-major (w * half + hi << lb), or just hi << lb with shared buckets
       uint32_t key_base;
       if (p.shared)
-        key_base = (b / p.windows) << p.lb;
+        key_base = ((b / p.levels) / p.b1) * p.half + (((b / p.levels) % p.b1) << p.lb);   // bucket set g, top bits hi
       else
         key_base = (b / p.b1) * p.half + ((b % p.b1) << p.lb);
       segs[b] = PartSeg{start, col, key_base, 0};
@@ -369,31 +387,32 @@ __global__ void __launch_bounds__(256) k_l1_scan_c(uint32_t* __restrict__ matrix
   }
 }
 
-// With shared buckets the segments of the next pass are the b1 bucket ranges, each the union of `windows` neighbouring bins.
+// With table levels the segments of the next pass are the bsets * b1 bucket ranges, each the union of `levels` neighbouring bins.
 __global__ void __launch_bounds__(256) k_l1_merge_shared(const PartSeg* __restrict__ bins, PartPlan p, PartSeg* __restrict__ segs,
                                                          uint32_t* __restrict__ subjob_first, uint32_t* __restrict__ totals) {
-  // one block; b1 <= 1024 segments
+  // one block; bsets * b1 segments
   __shared__ uint32_t tmp[32];
-  for (uint32_t h0 = 0; h0 < p.b1; h0 += 256) {
+  const uint32_t nseg = p.bsets * p.b1;
+  for (uint32_t h0 = 0; h0 < nseg; h0 += 256) {
     const uint32_t h = h0 + threadIdx.x;
     uint32_t len = 0, start = 0;
-    if (h < p.b1) {
-      start = bins[h * p.windows].start;
-      for (uint32_t w = 0; w < p.windows; w++) len += bins[h * p.windows + w].len;
+    if (h < nseg) {
+      start = bins[h * p.levels].start;
+      for (uint32_t j = 0; j < p.levels; j++) len += bins[h * p.levels + j].len;
     }
     const uint32_t nsj = part_subjobs_of(len);
     uint32_t tot;
     const uint32_t before = block_excl_scan(nsj, tmp, tot);
     const uint32_t base = h0 == 0 ? 0 : subjob_first[h0];
-    if (h < p.b1) {
-      segs[h] = PartSeg{start, len, h << p.lb, 0};
+    if (h < nseg) {
+      segs[h] = PartSeg{start, len, (h / p.b1) * p.half + ((h % p.b1) << p.lb), 0};
       subjob_first[h] = base + before;
     }
     __syncthreads();
-    if (threadIdx.x == 0) subjob_first[min(h0 + 256, p.b1)] = base + tot;
+    if (threadIdx.x == 0) subjob_first[min(h0 + 256, nseg)] = base + tot;
     __syncthreads();
   }
-  if (threadIdx.x == 0) totals[1] = subjob_first[p.b1];
+  if (threadIdx.x == 0) totals[1] = subjob_first[nseg];
 }
 
 // L1 scatter: one block per tile; the tile's scalars stay in registers while the windows are processed one after the other.
@@ -420,7 +439,7 @@ __global__ void __launch_bounds__(PART_THREADS) k_l1_scatter(const uint32_t* __r
     const uint32_t i = i0 + threadIdx.x + k * PART_THREADS;
     if (i < p.n) {
       load_scalar<FR, MONT>(st[k], scalars, i);
-      if (p.table_stride || inf[p.idx0 + i] == 0) alive |= 1u << k;
+      if (p.table_stride || inf[p.idx0 + i] == 0) alive |= 1u << k;   // (with tables the flag is read per level, below)
     } else {
 #pragma unroll
       for (int j = 0; j < 8; j++) st[k].s[j] = 0;
@@ -447,7 +466,7 @@ __global__ void __launch_bounds__(PART_THREADS) k_l1_scatter(const uint32_t* __r
       }
     }
   }
-  uint32_t offs_next = threadIdx.x < p.b1 ? row[p.shared ? threadIdx.x * p.windows + w_lo : w_lo * p.b1 + threadIdx.x] : 0;
+  uint32_t offs_next = threadIdx.x < p.b1 ? row[l1_bin_of(p, w_lo, threadIdx.x)] : 0;
   if (threadIdx.x < p.b1) cnt[threadIdx.x] = 0;
   lds_barrier();
   // Barriers per window: after the ranking (A), two inside the scan, after the scan step (B), after staging (C).  cnt is zeroed and
@@ -482,7 +501,7 @@ __global__ void __launch_bounds__(PART_THREADS) k_l1_scatter(const uint32_t* __r
       next_digit<FOLD>(st[k], raw[k] & wmask, p.c, p.half, wmask, ((alive >> (8 + k)) & 1) != 0, rwin, mag, neg);
       const uint32_t i = i0 + threadIdx.x + k * PART_THREADS;
       bool ok = ((alive >> k) & 1) && mag != 0;
-      const uint32_t idx = p.idx0 + i + w * p.table_stride;
+      const uint32_t idx = l1_base_index(p, i, w);
       if (ok && p.table_stride) ok = inf[idx] == 0;
       where[k] = 0xffffffffu;
       const uint32_t bucket = ok ? mag - 1 : 0, hi = bucket >> p.lb;
@@ -506,7 +525,7 @@ __global__ void __launch_bounds__(PART_THREADS) k_l1_scatter(const uint32_t* __r
         tstart[threadIdx.x] = ex;
         offs[threadIdx.x] = offs_next - ex;   // global position of staged slot j of this bin = offs[bin] + j: one LDS read per entry on the way out
         cnt[threadIdx.x] = 0;
-        if (w + 1 < w_hi) offs_next = row[p.shared ? threadIdx.x * p.windows + (w + 1) : (w + 1) * p.b1 + threadIdx.x];
+        if (w + 1 < w_hi) offs_next = row[l1_bin_of(p, w + 1, threadIdx.x)];
       }
       if (threadIdx.x == 0) tstart[p.b1] = tot;
     }
@@ -514,7 +533,7 @@ __global__ void __launch_bounds__(PART_THREADS) k_l1_scatter(const uint32_t* __r
 #pragma unroll
     for (int k = 0; k < PART_PER_THREAD; k++)
       if (where[k] != 0xffffffffu) {
-        const uint32_t idx = p.idx0 + i0 + threadIdx.x + k * PART_THREADS + w * p.table_stride;
+        const uint32_t idx = l1_base_index(p, i0 + threadIdx.x + k * PART_THREADS, w);
         // (value = base index | sign << 31; key word while staged: the bits still unresolved with the bin above them)
         stage[tstart[where[k] >> 16] + (where[k] & 0xffffu)] = make_uint2(idx | (low[k] & 0x80000000u), (low[k] & 0xffffu) | (where[k] & 0xffff0000u));
       }
@@ -830,7 +849,7 @@ __global__ void __launch_bounds__(256) k_dbg_count_digits(const uint32_t* __rest
       uint32_t mag;
       bool neg;
       next_digit<FOLD>(st, u, p.c, p.half, wmask, flip, FOLD ? fr_window<FR>(w, p.c, wmask) : 0u, mag, neg);
-      const bool dead = inf[p.idx0 + i + w * p.table_stride] != 0;
+      const bool dead = inf[l1_base_index(p, i, w)] != 0;
       if (mag != 0 && !dead) count++;
     }
   }
@@ -943,7 +962,7 @@ inline int part_run(const uint32_t* d_scalars, const uint8_t* d_inf, const PartP
   if (p.shared) {
     hipLaunchKernelGGL(k_l1_merge_shared, dim3(1), dim3(256), 0, st, b.segs[0], p, b.segs[1], b.subjob_first, b.totals);
     seg_cur = 1;
-    nsegs = p.b1;
+    nsegs = (uint64_t)p.bsets * p.b1;
   }
   if (p.fold)
     hipLaunchKernelGGL((k_l1_scatter<FR, MONT, true>), dim3(l1_grid), dim3(PART_THREADS), 0, st, d_scalars, d_inf, p, b.matrix, b.entries[0]);
@@ -966,7 +985,7 @@ inline int part_run(const uint32_t* d_scalars, const uint8_t* d_inf, const PartP
     PartSeg* out_segs = pp.last ? nullptr : b.segs[seg_cur ^ 1];
     // no segment can hold more entries than its window has scalars (all windows together when they share their buckets): below
     // PART_SUBJOB there are no long segments, hence no sub-jobs, and k_pass_hist / k_pass_scan have nothing to prepare
-    const bool long_segs = !part_fused_takes((uint32_t)std::min<uint64_t>((uint64_t)p.n * (p.shared ? p.windows : 1), 0xffffffffu));
+    const bool long_segs = !part_fused_takes((uint32_t)std::min<uint64_t>((uint64_t)p.n * p.levels, 0xffffffffu));
     const uint32_t gen = long_segs ? std::min<uint32_t>(pp.max_subjobs, PART_GEN_GRID) : 0;
     if (long_segs) {
       hipLaunchKernelGGL(k_pass_hist, dim3(std::min<uint32_t>(pp.max_subjobs, 2048u)), dim3(1024), 0, st, b.entries[cur], b.segs[seg_cur], b.subjob_first, pp,
@@ -989,8 +1008,8 @@ inline int part_run(const uint32_t* d_scalars, const uint8_t* d_inf, const PartP
   }
 #ifdef MSM_DEBUG
   {
-    const uint32_t key_limit = (p.shared ? 1u : p.windows) * p.half;
-    const uint32_t idx_hi = p.idx0 + p.n + (p.windows - 1) * p.table_stride;
+    const uint32_t key_limit = p.bsets * p.half;
+    const uint32_t idx_hi = p.idx0 + p.n + (p.levels - 1) * p.table_stride;
     if (getenv("MI355_MSM_DEBUG_CORRUPT")) hipLaunchKernelGGL(k_dbg_corrupt, dim3(1), dim3(1), 0, st, b.entries[cur], b.totals);
     hipLaunchKernelGGL(k_dbg_check_sorted, dim3(2048), dim3(256), 0, st, b.entries[cur], b.totals, key_limit, p.idx0, idx_hi, dbg);
     if (p.fold)

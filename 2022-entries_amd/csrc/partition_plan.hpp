@@ -40,7 +40,10 @@ struct PartSeg {          // a run of entries that share their high key bits
 // Geometry of one grouping problem, filled by the host (part_plan in msm_engine.hip).
 struct PartPlan {
   uint32_t n, c, windows, half;      // scalars, window bits, digit windows, 2^(c-1)
-  uint32_t shared;                   // 1: precomputed tables, all windows share one bucket set
+  uint32_t shared;                   // 1: precomputed tables -- windows that differ by a multiple of `bsets` share a bucket set
+  uint32_t levels, bsets;            // table levels k and bucket sets G = ceil(windows / k): window w = g + G j reads table level j (base index
+                                     // + j * table_stride) into bucket set g.  No tables: levels = 1, bsets = windows.  Tables for every window
+                                     // (the round-1..3 form): levels = windows, bsets = 1.
   uint32_t idx0, table_stride;       // base index of scalar 0, distance between table levels
   uint32_t hb, lb;                   // bucket bits resolved by level 1 / left after it (hb + lb = c - 1)
   uint32_t b1;                       // 2^hb
@@ -62,15 +65,19 @@ struct PassPlan {
 
 inline uint32_t part_ceil_div(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
 
-// `shared` = all windows feed one bucket set (precomputed tables).
-inline PartPlan part_plan(uint32_t n, uint32_t c, uint32_t windows, bool shared, uint32_t idx0, uint32_t table_stride, bool fold = false) {
+// `levels` = precomputed table levels (0 or 1: none).  With k levels the windows g, g + G, g + 2G, ... (G = ceil(windows / k)) feed bucket
+// set g: yrrid's shape is k = 6, G = 2 (CMB PrecomputePoints.cu:10-39, MSM.cu:380-383); k >= windows is "one bucket set for all".
+inline PartPlan part_plan(uint32_t n, uint32_t c, uint32_t windows, uint32_t levels, uint32_t idx0, uint32_t table_stride, bool fold = false) {
   PartPlan p{};
   p.fold = fold ? 1 : 0;
   p.n = n;
   p.c = c;
   p.windows = windows;
   p.half = 1u << (c - 1);
-  p.shared = shared ? 1 : 0;
+  p.levels = levels > 1 ? std::min(levels, windows) : 1;
+  p.bsets = part_ceil_div(windows, p.levels);
+  p.levels = part_ceil_div(windows, p.bsets);      // (no level without a window: 13 windows in 6 levels are 3 sets x 5 levels)
+  p.shared = p.levels > 1 ? 1 : 0;
   p.idx0 = idx0;
   p.table_stride = table_stride;
   // Level 1 resolves as many bucket bits as it can (it is fused with the digit extraction, so its bits are the cheap ones)
@@ -90,7 +97,7 @@ inline PartPlan part_plan(uint32_t n, uint32_t c, uint32_t windows, bool shared,
     p.hb = bits - (uint32_t)PART_MAX_RB;
   p.lb = bits - p.hb;
   p.b1 = 1u << p.hb;
-  p.nbins = windows * p.b1;
+  p.nbins = p.bsets * p.levels * p.b1;   // (= windows * b1 without tables; with them a few bins of the last level may stay empty)
   p.ntiles = part_ceil_div(n, PART_TILE);
   if (p.ntiles == 0) p.ntiles = 1;
   p.tiles_per_group = part_ceil_div(p.ntiles, PART_SCAN_GROUPS);
@@ -148,7 +155,7 @@ inline PartScratchSizes part_scratch_sizes(const PartPlan& p) {
   uint32_t rb[4];
   const int np = part_pass_bits(p.lb, rb);
   // segment counts per level: level 1 -> nbins (or b1 merged segments when shared), then x 2^rb per pass
-  uint64_t nsegs = p.shared ? p.b1 : p.nbins, max_segs = p.nbins, max_counts = 0, max_sj = 0;
+  uint64_t nsegs = p.shared ? (uint64_t)p.bsets * p.b1 : p.nbins, max_segs = p.nbins, max_counts = 0, max_sj = 0;
   for (int i = 0; i < np; i++) {
     const uint64_t sj = part_max_subjobs(entries, nsegs);
     max_counts = std::max<uint64_t>(max_counts, sj << rb[i]);

@@ -350,9 +350,9 @@ def msm(bases, scalars, curve="bls12_377_g1") -> bytes:
 
 def last_stateless() -> dict:
     """What this thread's most recent stateless ``msm`` call did (mi355_msm_last_stateless)."""
-    v = (ctypes.c_double * 8)()
-    _check(load_library().mi355_msm_last_stateless(v, 8))
-    names = ("total_ms", "setup_ms", "wait_upload_ms", "compute_ms", "tail_ms", "slices", "threads", "bytes")
+    v = (ctypes.c_double * 10)()
+    _check(load_library().mi355_msm_last_stateless(v, 10))
+    names = ("total_ms", "setup_ms", "wait_upload_ms", "compute_ms", "tail_ms", "slices", "threads", "bytes", "dma_done_ms", "first_dma_ms")
     return {k: float(v[i]) for i, k in enumerate(names)}
 
 

@@ -507,28 +507,60 @@ def main():
                                              f"arkworks-algorithm restatement (c={c}, one thread per window), host has {cores} cores",
                                    "gpu_matches_cpu_on_sample": gpu_res == cpu_res}
         if world == 1 and not c_sharded and args.also_precompute and not args.precompute and cid < 2:
-            # the reference's own convention (init untimed, tables built there): reported next to the headline, not as it
+            # The reference's own convention (P1A combined-top-solutions/benches/msm.rs:21,27-35; CMB MSM.cu:380-383): `init` builds the
+            # precomputed tables untimed, then FOUR batches of scalars come from pageable host memory.  Reported next to the headline,
+            # never as it.  table_levels = k: k levels 2^(c G j) P, windows g, g + G, ... share bucket set g (yrrid: k = 6, G = 2);
+            # 0 = a level per window (one bucket set).  Per k: ms per MSM with resident scalars, HBM held by the tables, init seconds;
+            # and for every k the ZPrize workload itself (4 x 2^npow scalars from pageable host memory, one call).
             try:
                 ctx.close()   # give the headline context's ~40 GB back before the tables (95 + 142 GB while they are converted)
-                ctx2 = ea.MultiScalarMultContext(args.curve, device=local_rank)
-                ctx2.set_option("precompute", 1)
-                t_i = time.perf_counter()
-                ctx2.set_bases(tile.repeat(n // distinct, 1).contiguous())
-                torch.cuda.synchronize()
-                t_i = time.perf_counter() - t_i
-                r2 = ctx2.run(scalars)[0]
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                for _ in range(args.steps):
-                    r2 = ctx2.run(scalars)[0]
-                torch.cuda.synchronize()
-                dt2 = time.perf_counter() - t1
-                tm2 = ctx2.last_timings()
-                out["with_precomputed_tables"] = {"ms_per_step": dt2 / args.steps * 1e3, "value": n * args.steps / dt2, "unit": "pairs/s",
-                                                  "init_s": t_i, "window_bits": tm2["window_bits"], "windows": tm2["windows"],
-                                                  "accumulate_ms": tm2["accumulate"], "same_result_as_headline_path": r2 == result}
-                ctx2.close()
-            except Exception as e:  # e.g. not enough free HBM for the tables
+                sc4p = None
+                if args.extras:
+                    sc4p = torch.cat([uniform_scalars(n, R381_TOP if cid in (1, 3) else R377_TOP, device, seed=4000 + b) for b in range(4)]).cpu().numpy()
+                table = {}
+                for levels in ((0, 6, 3, 2) if args.npow >= 20 else (0, 6)):
+                    name = "all" if levels == 0 else str(levels)
+                    try:
+                        ctx2 = ea.MultiScalarMultContext(args.curve, device=local_rank)
+                        ctx2.set_option("precompute", 1)
+                        ctx2.set_option("table_levels", levels)
+                        t_i = time.perf_counter()
+                        ctx2.set_bases(tile.repeat(n // distinct, 1).contiguous())
+                        torch.cuda.synchronize()
+                        t_i = time.perf_counter() - t_i
+                        r2 = ctx2.run(scalars)[0]
+                        torch.cuda.synchronize()
+                        t1 = time.perf_counter()
+                        for _ in range(args.steps):
+                            r2 = ctx2.run(scalars)[0]
+                        torch.cuda.synchronize()
+                        dt2 = time.perf_counter() - t1
+                        tm2 = ctx2.last_timings()
+                        row = {"ms_per_step": dt2 / args.steps * 1e3, "value": n * args.steps / dt2, "unit": "pairs/s", "init_s": t_i,
+                               "table_levels": ctx2.query("table_levels"), "window_bits": tm2["window_bits"], "windows": tm2["windows"],
+                               "bucket_sets": -(-tm2["windows"] // max(1, ctx2.query("table_levels"))),
+                               "table_bytes": ctx2.query("base_bytes"), "group_law": "twisted Edwards" if ctx2.query("twisted_edwards") else "XYZZ",
+                               "stage_ms": {k: tm2[k] for k in ("digits", "sort", "accumulate", "segreduce", "bucket_reduce")},
+                               "same_result_as_headline_path": r2 == result}
+                        if sc4p is not None:
+                            ms4, r4t = timed(lambda: ctx2.run(sc4p), 2)
+                            row["four_batches_from_pageable_host_ms"] = ms4
+                        ctx2.close()
+                        table[name] = row
+                    except Exception as e:  # e.g. not enough free HBM for the tables
+                        table[name] = {"error": str(e)}
+                del sc4p
+                out["with_precomputed_tables"] = dict(table.get("all", {}), by_table_levels=table,
+                                                      what="context option precompute = 1 (init untimed, as the reference's bench does); by_table_levels: k -> the "
+                                                           "same workload with k table levels; four_batches_from_pageable_host_ms is the ZPrize workload "
+                                                           "(reference: 2200-2300 ms on an A40 with 6 levels)")
+                ok_rows = {k: v for k, v in table.items() if "error" not in v and "four_batches_from_pageable_host_ms" in v}
+                if ok_rows and "survey_8d_metrics" in out and "host_scalars" in out["survey_8d_metrics"]:
+                    best = min(ok_rows, key=lambda k: ok_rows[k]["four_batches_from_pageable_host_ms"])
+                    out["survey_8d_metrics"]["host_scalars"]["four_batches_ms"]["precompute"] = {
+                        k: v["four_batches_from_pageable_host_ms"] for k, v in ok_rows.items()}
+                    out["survey_8d_metrics"]["host_scalars"]["four_batches_ms"]["precompute_best_table_levels"] = best
+            except Exception as e:
                 out["with_precomputed_tables"] = {"error": str(e)}
         print(json.dumps(out), flush=True)
     ctx.close()

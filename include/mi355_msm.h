@@ -181,7 +181,9 @@ RustError mi355_msm(int curve, void* out_projective, const void* affine, size_t 
  * With MI355_MSM_DEVICES naming several GPUs every shard runs its own pipeline over its slice of both operands.
  * mi355_msm_last_stateless: what the calling thread's most recent stateless call did -- out[0..7] = total ms, setup ms (buffers,
  * ring, threads), ms the compute side waited for uploads, ms it spent issuing/awaiting slices, the last slice's share of that
- * (the tail nothing overlaps), slices, staging threads, bytes moved. */
+ * (the tail nothing overlaps), slices, staging threads, bytes moved; out[8] = ms from the start of the call to the completion of its LAST
+ * DMA (total ms - out[8] is what the call spends after the uploads are over: the bound is PCIe when that is one slice's compute,
+ * the device when it is more), out[9] = ms at which the copy stream started. */
 RustError mi355_msm_last_stateless(double* out, size_t count);
 /* What the stateless entry points keep between calls, and its bounds: the pinned staging rings (12 x 16 MiB per device in use) and at
  * most ONE idle context per (curve, device) with its device buffers (~9 GB after a 2^26-pair G1 call; a context above

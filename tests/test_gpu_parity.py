@@ -275,6 +275,54 @@ def test_precomputed_tables(ea, oracle, golden, torch_cuda, cid, curve):
         ctx.close()
 
 
+@pytest.mark.parametrize("curve_name,cid,rid", [("bls12_377_g1", 0, 0), ("bls12_381_g1", 1, 1), ("bls12_377_g2", 2, 0)])
+def test_table_levels(ea, oracle, golden, torch_cuda, curve_name, cid, rid):
+    """Row f1, the reference's own shape: k table levels 2^(c G j) P, windows g, g + G, ... sharing bucket set g (yrrid: k = 6, two
+    bucket sets -- CMB PrecomputePoints.cu:10-39, MSM.cu:380-383).  Every k gives the oracle's bytes: random inputs with an
+    infinity base, two batches, chunking over carried buckets, forced window sizes (incl. one whose windows do not divide by k),
+    the low-order edge points of the golden vectors (their multiples hit infinity inside the tables)."""
+    import ctypes
+
+    stride = ea.affine_stride(curve_name)
+    n = 6000
+    bases = ea.generate_points(n, distinct=300, seed=21, curve=curve_name)
+    bases[11, stride - 8] = 1
+    scalars = rand_scalars_np(rid, 2 * n, 77)
+    exp = []
+    for b in range(2):
+        out = ctypes.create_string_buffer(ea.projective_bytes(curve_name))
+        sc = np.ascontiguousarray(scalars[b * n:(b + 1) * n])
+        assert oracle.oracle_msm(cid, bases.ctypes.data, stride, sc.ctypes.data, n, out, 0) == 0
+        exp.append(out.raw)
+    for levels, wb in ((2, 0), (3, 0), (6, 0), (6, 7), (5, 11), (40, 9), (2, 13)):
+        ctx = ea.MultiScalarMultContext(curve_name)
+        ctx.set_option("precompute", 1)
+        ctx.set_option("table_levels", levels)
+        if wb:
+            ctx.set_option("window_bits", wb)
+        ctx.set_bases(bases)
+        t_levels, c = ctx.query("table_levels"), ctx.query("table_window_bits")
+        windows = -(-257 // c)
+        sets = -(-windows // min(levels, windows))
+        assert t_levels == -(-windows // sets), (levels, wb, t_levels, c)
+        assert ctx.run(scalars) == exp, (levels, wb)
+        assert ctx.last_timings()["tables"]
+        ctx.set_option("max_chunk", 2500)
+        assert ctx.run(scalars) == exp, (levels, wb, "chunked")
+        ctx.close()
+    for case in golden:
+        if case["curve"] != curve_name:
+            continue
+        b, sc = bytes.fromhex(case["bases"]), bytes.fromhex(case["scalars"])
+        ctx = ea.MultiScalarMultContext(curve_name)
+        ctx.set_option("precompute", 1)
+        ctx.set_option("table_levels", 3)
+        ctx.set_option("window_bits", 6)
+        ctx.set_bases(b)
+        assert ctx.run(sc)[0].hex() == case["expected"], case["name"]
+        ctx.close()
+
+
 def test_prefix_run_and_errors(ea, oracle, torch_cuda):
     c = m.BLS12_377_G1
     n = 600

@@ -1,7 +1,8 @@
 // partition_test.hip -- standalone check + timing of the bucket-grouping kernels (csrc/partition.hpp) against a CPU model:
 // every (key, value) entry the digits of the scalars define must come out exactly once, keys non-decreasing, nothing else.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++20 tools/partition_test.hip -o tools/partition_test
-//   tools/partition_test [npow=20] [c=0 (auto)] [shared=0] [pattern=0 uniform|1 all-equal|2 small|3 zeros+ones] [reps=3]
+//   tools/partition_test [npow=20] [c=0 (auto)] [levels=0 (no tables) | 1 (a table level per window) | k (k levels: windows g, g + G, ...
+//                        share bucket set g)] [pattern=0 uniform|1 all-equal|2 small|3 zeros+ones] [reps=3]
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -21,16 +22,20 @@ struct Agg { uint64_t count = 0, sum = 0, x = 0; };
 int main(int argc, char** argv) {
   const int npow = argc > 1 ? atoi(argv[1]) : 20;
   uint32_t c = argc > 2 ? atoi(argv[2]) : 0;
-  const bool shared = argc > 3 ? atoi(argv[3]) != 0 : false;
+  const int levels_arg = argc > 3 ? atoi(argv[3]) : 0;
+  const bool shared = levels_arg != 0;
   const int pattern = argc > 4 ? atoi(argv[4]) : 0;
   const int reps = argc > 5 ? atoi(argv[5]) : 3;
   const uint32_t n = npow >= 0 ? (1u << npow) : (uint32_t)(-npow);   // negative: a literal (ragged) count
   if (!c) c = npow >= 24 ? 20 : (npow >= 16 ? 14 : 9);
   const uint32_t windows = (257 + c - 1) / c;
+  uint32_t levels = !shared ? 1 : (levels_arg == 1 ? windows : std::min<uint32_t>((uint32_t)levels_arg, windows));
+  const uint32_t bsets = (windows + levels - 1) / levels;
+  levels = (windows + bsets - 1) / bsets;
   const uint32_t table_stride = shared ? n : 0;
   const uint32_t idx0 = shared ? 0 : 5;   // a chunk offset
-  const size_t nbases = shared ? (size_t)windows * n : n + idx0;
-  printf("n=%u c=%u windows=%u shared=%d pattern=%d\n", n, c, windows, (int)shared, pattern);
+  const size_t nbases = shared ? (size_t)levels * n : n + idx0;
+  printf("n=%u c=%u windows=%u levels=%u bucket_sets=%u pattern=%d\n", n, c, windows, levels, bsets, pattern);
 
   std::mt19937_64 rng(1234 + npow + pattern);
   std::vector<uint64_t> sc((size_t)n * 4);
@@ -63,9 +68,9 @@ int main(int argc, char** argv) {
         const bool neg = v > half;
         const uint32_t d = neg ? (1u << c) - v : v;
         carry = neg;
-        const uint32_t idx = idx0 + i + w * table_stride;
+        const uint32_t idx = idx0 + i + (w / bsets) * table_stride;
         if (d == 0 || inf[idx]) continue;
-        const uint32_t key = (shared ? 0 : w * half) + d - 1;
+        const uint32_t key = (w % bsets) * half + d - 1;
         const uint32_t val = idx | (neg ? 0x80000000u : 0);
         Agg& a = want[key];
         a.count++; a.sum += val; a.x ^= (uint64_t)val * 0x9e3779b97f4a7c15ull;
@@ -74,7 +79,7 @@ int main(int argc, char** argv) {
     }
   }
 
-  const PartPlan p = part_plan(n, c, windows, shared, idx0, table_stride);
+  const PartPlan p = part_plan(n, c, windows, shared ? levels : 1, idx0, table_stride);
   const PartScratchSizes sz = part_scratch_sizes(p);
   const uint64_t E = (uint64_t)n * windows;
   printf("hb=%u lb=%u nbins=%u ntiles=%u  scratch: matrix %.1f MB counts %.1f MB segs %.1f MB\n", p.hb, p.lb, p.nbins, p.ntiles,
