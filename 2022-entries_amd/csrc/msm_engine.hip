@@ -160,9 +160,15 @@ int choose_window_bits(size_t n, int scalar_bits, bool shared_buckets, bool fold
     if (n < ((size_t)3 << 14)) return 8;
     if (n < ((size_t)3 << (scalar_bits > 253 ? 16 : 17))) return 11;
   }
+  // Tables pay only where they buy a window: with the same number of windows as the table-free plan the additions are the same and
+  // the gathers out of tens of GB of tables cost 3 % more (2^26: c = 21 with 2..6 levels 112 ms against 106 without tables; c = 23
+  // with 6 levels 102.4 ms -- profiles/r04_table_levels_sweep.txt).  So a plan with tables only considers window sizes with FEWER
+  // windows than the table-free choice.
+  const int free_wins = shared_buckets ? (257 + choose_window_bits(n, scalar_bits, false, fold) - 1) / choose_window_bits(n, scalar_bits, false, fold) : 0;
   int best = 2;
   double best_cost = 1e300;
   for (int c = 2; c <= (shared_buckets ? 24 : 23); c++) {
+    if (shared_buckets && c < 24 && (257 + c - 1) / c >= free_wins) continue;
     // folded scalars (assume_subgroup) are < r/2: one bit less, and when c divides that the window above only takes the carry
     // of the scalars whose top digit exceeds 2^(c-1): (r/2 - 2^(bits-1)) / (r/2) = 14.5 % (BLS12-377), 44.8 % (BLS12-381)
     // (only from 2^25 pairs on: that is where it was measured to pay -- BLS12-377 G1 2^26, c = 21: 110.2 -> 108.3 ms; below, the model's

@@ -73,6 +73,36 @@ def kernel_source_sha16():
     return h.hexdigest()[:16]
 
 
+HBM_ACHIEVABLE_GBPS = 6300.0    # MI355X_MICROARCH.md: what a streaming kernel reaches of the 8 TB/s
+
+
+def stage_roofline(n, tm, ms, cid):
+    """The HBM-bound stages against HBM: STRUCTURAL bytes each stage has to move once, over its measured time,
+    as a fraction of the achievable streaming rate.  digits = level 1 of the grouping (scalars read twice, the tile x bin count
+    matrix written once and read/written by the column scan and read by the scatter, the entries written); sort = the generic
+    pass (entries in from HBM, entries out; the fused kernel's second read comes from cache and is not counted); bucket_reduce =
+    every bucket read once."""
+    W, c = tm["windows"], tm["window_bits"]
+    E = tm["entries"]
+    lg = n.bit_length() - 1
+    hb = min(c - 1, 10, max(0, lg - 15))
+    if c - 1 - hb > 10 and c - 1 - 10 <= 10:
+        hb = c - 1 - 10
+    ntiles = -(-n // 8192)
+    matrix = ntiles * W * (1 << hb) * 4
+    passes = max(1, -(-(c - 1 - hb) // 10))
+    xyzz = 448 if cid >= 2 else 224
+    bsets = 1 if tm["tables"] else W
+    stages = {"digits": 2 * 32 * n + 5 * matrix + 8 * E, "sort": passes * 16 * E, "bucket_reduce": bsets * (1 << (c - 1)) * xyzz}
+    out = {}
+    for k, b in stages.items():
+        if ms.get(k):
+            gbps = b / (ms[k] * 1e-3) / 1e9
+            out[k] = {"structural_bytes": b, "ms": ms[k], "GBps": gbps, "frac_of_achievable": gbps / HBM_ACHIEVABLE_GBPS}
+    out["achievable_GBps"] = HBM_ACHIEVABLE_GBPS
+    return out
+
+
 def timed(fn, reps):
     """Wall ms per call of fn() (each call returns with the result on the host, i.e. it is synchronous)."""
     fn()
@@ -351,6 +381,7 @@ def main():
                                        f"{'RCCL all-gather' if ctx_rccl else 'host fold'} of {args.gpus} partial points" if c_sharded else
                                        f"{world} disjoint base/scalar slices + all-gather of {world} partial points")},
             "stage_ms_per_step": {k: v / args.steps for k, v in stage_ms.items()},
+            "stage_roofline": stage_roofline(n, tm, {k: v / args.steps for k, v in stage_ms.items()}, cid),
             "per_rank": per_rank,
             "weak_scaling_point": weak_point,
             "roofline": {"bound": "hbm", "kernel": "k_accumulate_glds", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
