@@ -27,5 +27,5 @@ for slog, down, carry, cc in shapes:
         t0 = time.perf_counter(); r = ea.msm(bases_host, sc_host, curve); best = min(best, time.perf_counter() - t0)
     ref = ref or r
     st = ea.last_stateless()
-    print("slice 2^%d ramp-down %d carry %d (c %s): %.1f ms  same=%s  waited-for-upload %.1f  issue/await %.1f (after the last upload %.1f)  slices %d" % (
-        slog, down, carry, cc or "auto", best * 1e3, r == ref, st["wait_upload_ms"], st["compute_ms"], st["tail_ms"], st["slices"]), flush=True)
+    print("slice 2^%d ramp-down %d carry %d (c %s): %.1f ms  same=%s  waited-for-upload %.1f  issue/await %.1f (after the last upload %.1f)  last DMA done @%.1f  slices %d" % (
+        slog, down, carry, cc or "auto", best * 1e3, r == ref, st["wait_upload_ms"], st["compute_ms"], st["tail_ms"], st.get("dma_done_ms", 0.0), st["slices"]), flush=True)
