@@ -169,6 +169,9 @@ int choose_window_bits(size_t n, int scalar_bits, bool shared_buckets, bool fold
   double best_cost = 1e300;
   for (int c = 2; c <= (shared_buckets ? 24 : 23); c++) {
     if (shared_buckets && c < 24 && (257 + c - 1) / c >= free_wins) continue;
+    // c = 22 leaves 11 bits after level 1: a first generic pass over ONE bit (2 counters for 16384 entries of a tile) and segments
+    // of 196 K entries for the second; it has the 12 windows of c = 23 and measures 10 % slower (same file)
+    if (shared_buckets && c == 22) continue;
     // folded scalars (assume_subgroup) are < r/2: one bit less, and when c divides that the window above only takes the carry
     // of the scalars whose top digit exceeds 2^(c-1): (r/2 - 2^(bits-1)) / (r/2) = 14.5 % (BLS12-377), 44.8 % (BLS12-381)
     // (only from 2^25 pairs on: that is where it was measured to pay -- BLS12-377 G1 2^26, c = 21: 110.2 -> 108.3 ms; below, the model's
@@ -307,7 +310,10 @@ struct mi355_msm_ctx {
     p.scan_direct = p.reduce_scan && p.half <= (1u << scan_log);
     if (p.reduce_scan && !p.scan_direct) {
       const uint32_t need = ilog2_floor(p.half) - scan_log;   // first-level chunk size that leaves 2^scan_log chunks
-      if (need > 9)
+      // the chunked level leaves 4096 chunks per bucket window: with the few bucket sets of a table plan (1..6) that is a few thousand
+      // lanes walking 512 buckets each on a chip of 65536 -- c = 22 with tables: 9.3 ms of bucket reduction against 3.6 at c = 23,
+      // which already took the recursive scheme (profiles/r04_table_levels_sweep.txt)
+      if (need > 9 || (need > 8 && p.bucket_windows < 8))
         p.reduce_scan = false;   // windows beyond 2^21 buckets (precomputed tables): keep the recursive scheme and ITS chunk sizes
       else if (p.logL0 < need)
         p.logL0 = need;
