@@ -55,8 +55,10 @@ for case in range(cases):
     shards = rng.choice([0, 0, 0, 2, 5])     # 0: ordinary context; else that many logical shards behind the C ABI
     ctx = ea.MultiScalarMultContext(name, devices=[0] * shards) if shards else ea.MultiScalarMultContext(name)
     opts = {"shards": shards} if shards else {}
-    if rng.random() < 0.3:
+    if rng.random() < 0.35:
         opts["precompute"] = 1
+        if rng.random() < 0.6:
+            opts["table_levels"] = rng.choice([2, 3, 4, 6, 9])      # round 4: k levels, ceil(W / k) bucket sets
     if rng.random() < 0.5:
         opts["window_bits"] = rng.randrange(2, 25) if rng.random() < 0.3 else rng.randrange(2, 18)
     if cid == 0 and rng.random() < 0.25:
@@ -79,6 +81,11 @@ for case in range(cases):
         ctx.set_option("assume_subgroup", 1); opts["fold"] = 1  # the generator's points are multiples of G: scalars above r/2 fold
     got = ctx.run(torch.from_numpy(sc).cuda() if rng.random() < 0.5 else sc)[0]
     ctx.close()
+    if rng.random() < 0.15 and not shards:
+        # the stateless call on the same operands (the pipeline, the bounded pool)
+        if ea.msm(bases, sc, name) != got:
+            bad += 1
+            print("MISMATCH stateless vs context", case, name, n, kind, opts, special, flush=True)
     out = ctypes.create_string_buffer(ea.projective_bytes(name))
     lib.oracle_msm(cid, bases.ctypes.data, stride, sc.ctypes.data, n, out, 0)
     if kind == 5:
