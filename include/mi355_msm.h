@@ -120,7 +120,12 @@ RustError mi355_msm_run_device(mi355_msm_ctx* ctx, void* out_projective, const v
 /* "precompute" = 1 (set BEFORE set_bases) makes the context store the tables 2^(c w) * P_i for every window w, so all digits
  * of a scalar share one bucket set and the bucket->window reduction and the window fold shrink by the number of windows --
  * the fixed-base trick of the ZPrize winners (CMB PrecomputePoints.cu:10-39; P1A matter-labs/src/lib.rs:101-114), paid for in
- * the untimed init and in HBM (windows x 128 B per base: 94 GB at 2^26).  Results are identical.
+ * the untimed init and in HBM (windows x 128 B per base: 94 GB at 2^26, 151 GB with the Edwards records).  Results are identical.
+ * "table_levels" = k (with "precompute", BEFORE set_bases; default 0 = a level per window) builds only k levels 2^(c G j) * P_i,
+ * j < k, for G = ceil(windows / k) bucket sets: window g + G j reads level j into bucket set g -- the reference's own shape is
+ * k = 6 levels and 2 bucket sets for its 23-bit windows (CMB PrecomputePoints.cu:10-39, MSM.cu:380-383).  k times the base memory
+ * instead of `windows` times; measured at 2^26 (profiles/r04_table_levels_sweep.txt): all levels 101 ms / 151 GB, k = 6 105 ms /
+ * 86 GB, k = 3 107 ms / 47 GB, no tables 108 ms / 21.5 GB.
  * Tuning knobs ("window_bits" 2..24, "lane_entries", "max_chunk" <= 2^27, "seg_entries" >= 4, "reduce_log_chunk" /
  * "reduce_log_chunk0" 1..7: bucket-reduction chunk sizes on all / the first level); 0 restores the automatic choice.
  * "reduce_scan" = 0 keeps the bucket reduction on the recursive chunked scheme only (default: its tail is a parallel scan);
@@ -152,7 +157,9 @@ RustError mi355_msm_set_option(mi355_msm_ctx* ctx, const char* key, long value);
  * the run is then repeated on the short-Weierstrass path.  Costs 192 B per base (per table level) of HBM on top. */
 /* State of a context: "twisted_edwards" (1 = the current bases run on the twisted-Edwards path), "twisted_edwards_fallbacks"
  * (chunks repeated on the XYZZ path so far), "twisted_edwards_demotions" (two fallbacks in a row demote the base set to XYZZ
- * until the next set_bases), "oom_backoffs" (chunks restarted at half size after a device allocation failed), "chunk_cap",
+ * until the next set_bases), "oom_backoffs" (chunks restarted at half size after a device allocation failed -- after the idle
+ * contexts of the stateless pool were given back and the same chunk retried), "debug_checks" (invariant checks a -DMSM_DEBUG
+ * build has run; always 0 in this library), "chunk_cap",
  * "device", "bases", "table_levels", "table_window_bits", "base_bytes" (device bytes held for the bases). */
 RustError mi355_msm_query(mi355_msm_ctx* ctx, const char* key, uint64_t* value);
 /* Per-stage device time (ms, HIP events on the launch stream) of the most recent run, summed over its chunks
