@@ -38,7 +38,7 @@ def hipcc() -> str:
     raise RuntimeError("hipcc not found: the MSM engine is HIP-only (no CPU fallback)")
 
 
-ENGINE_UNITS = ["msm_engine.hip", "partition.hip", "kernels_377g1.hip", "kernels_381g1.hip", "kernels_377g2.hip", "kernels_381g2.hip", "kernels_377te.hip"]
+ENGINE_UNITS = ["msm_engine.hip", "partition.hip", "kernels_377g1.hip", "kernels_381g1.hip", "kernels_377g2.hip", "kernels_381g2.hip", "kernels_377te.hip", "kernels_377g2p.hip", "kernels_381g2p.hip"]
 
 
 def _depfile_deps(dfile: str):

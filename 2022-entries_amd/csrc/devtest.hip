@@ -7,6 +7,7 @@
 #include <cstdio>
 
 #include "devtest_ops.hpp"
+#include "fp2pair.hpp"
 #include "host_curve.hpp"
 
 namespace msm {
@@ -37,6 +38,82 @@ __global__ void __launch_bounds__(64) k_devtest_quad(const uint32_t* __restrict_
   else
     te_add_quad<typename E::Fld>(a, b, q, md);
   dt_store(out + (size_t)i * 4 * EW + q * EW, a);
+}
+
+// two lanes per record (fp2pair.hpp): lane h of a pair holds half h (c0 / c1) of every Fp2 value of the record.  The same op table
+// as devtest_apply, instantiated over the paired coordinate policy; the limbs must equal the one-lane form's (and the host's).
+template <class PE>
+struct PairOf;
+template <class F, int NB>
+struct PairOf<Fp2El<F, NB>> {
+  using E = Fp2PairEl<F, NB>;
+};
+template <class C, int OP>
+__global__ void __launch_bounds__(64) k_devtest_pair(const uint32_t* __restrict__ in, int in_words, uint32_t* __restrict__ out, int out_words, uint32_t n) {
+  using E = typename PairOf<typename C::E>::E;
+  constexpr int EW = 2 * NL;
+  const uint32_t t = blockIdx.x * 64 + threadIdx.x;
+  const uint32_t i = t >> 1, h = t & 1;
+  if (i >= n) return;
+  const uint32_t* src = in + (size_t)i * in_words + h * NL;    // half h of element e starts at src + e * EW
+  uint32_t* dst = out + (size_t)i * out_words + h * NL;
+  typename E::Md md;
+  auto ld = [&](int e) { Fe r; dt_load(r, src + e * EW); return r; };
+  auto st = [&](int e, const Fe& v) { dt_store(dst + e * EW, v); };
+  if constexpr (OP == DT_EL_MUL || OP == DT_EL_MUL_C || OP == DT_EL_MUL_C_BIG) {
+    Fe a = ld(0), b = ld(1), r;
+    if constexpr (OP == DT_EL_MUL) E::mul(r, a, b, md);
+    else if constexpr (OP == DT_EL_MUL_C) E::template mul_c<false>(r, a, b, md);
+    else E::template mul_c<true>(r, a, b, md);
+    st(0, r);
+  } else if constexpr (OP == DT_EL_SQR || OP == DT_EL_SQR_C) {
+    Fe a = ld(0), r;
+    if constexpr (OP == DT_EL_SQR) E::sqr(r, a, md); else E::sqr_c(r, a, md);
+    st(0, r);
+  } else if constexpr (OP == DT_EL_MUL_SUB_C) {
+    Fe a = ld(0), b = ld(1), c = ld(2), d = ld(3), r;
+    E::mul_sub_c(r, a, b, c, d, md);
+    st(0, r);
+  } else if constexpr (OP == DT_MADD_COMMON || OP == DT_MADD) {
+    XyzzT<Fe> acc{ld(0), ld(1), ld(2), ld(3)};
+    AffineT<Fe> base{ld(4), ld(5)};
+    const uint32_t flags = in[(size_t)i * in_words + 6 * EW];
+    uint32_t ret = 0;
+    if constexpr (OP == DT_MADD_COMMON)
+      ret = xyzz_madd_common<E>(acc, base, (flags & 1) != 0, (flags & 2) != 0, md) ? 1u : 0u;
+    else
+      xyzz_madd<E>(acc, base, (flags & 1) != 0, (flags & 2) != 0, md);
+    st(0, acc.x); st(1, acc.y); st(2, acc.zz); st(3, acc.zzz);
+    if (h == 0) out[(size_t)i * out_words + 4 * EW] = ret;
+  } else if constexpr (OP == DT_ADD) {
+    XyzzT<Fe> acc{ld(0), ld(1), ld(2), ld(3)}, b{ld(4), ld(5), ld(6), ld(7)};
+    xyzz_add<E>(acc, b, md);
+    st(0, acc.x); st(1, acc.y); st(2, acc.zz); st(3, acc.zzz);
+  } else if constexpr (OP == DT_DBL) {
+    XyzzT<Fe> acc{ld(0), ld(1), ld(2), ld(3)};
+    xyzz_dbl<E>(acc, md);
+    st(0, acc.x); st(1, acc.y); st(2, acc.zz); st(3, acc.zzz);
+  }
+}
+
+template <class C>
+hipError_t launch_pair_op(int op, const uint32_t* d_in, int in_words, uint32_t* d_out, int out_words, uint32_t n) {
+  switch (op) {
+#define DT_PCASE(OP) case OP: hipLaunchKernelGGL((k_devtest_pair<C, OP>), dim3((2 * n + 63) / 64), dim3(64), 0, 0, d_in, in_words, d_out, out_words, n); return hipGetLastError();
+    DT_PCASE(DT_EL_MUL)
+    DT_PCASE(DT_EL_SQR)
+    DT_PCASE(DT_EL_MUL_C)
+    DT_PCASE(DT_EL_MUL_C_BIG)
+    DT_PCASE(DT_EL_SQR_C)
+    DT_PCASE(DT_EL_MUL_SUB_C)
+    DT_PCASE(DT_MADD_COMMON)
+    DT_PCASE(DT_MADD)
+    DT_PCASE(DT_ADD)
+    DT_PCASE(DT_DBL)
+#undef DT_PCASE
+    default: break;
+  }
+  return hipErrorInvalidValue;
 }
 
 template <class C, int OP>
@@ -91,6 +168,10 @@ extern "C" {
 // words per input / output record of `op` on `curve` (0/0 for an op the curve does not have)
 int msm_devtest_shape(int curve, int op, int* in_words, int* out_words) {
   if (!in_words || !out_words || curve < 0 || curve > 3) return -1;
+  if (op >= msm::DT_PAIR) {   // the two-lanes-per-record form of a G2 op: same records
+    op -= msm::DT_PAIR;
+    if (curve < 2 || op < msm::DT_EL_MUL || op > msm::DT_DBL) return -1;
+  }
   msm::devtest_shape(op, curve >= 2 ? 2 * msm::NL : msm::NL, *in_words, *out_words);
   if (curve != 0 && op >= msm::DT_TE_MADD && op <= msm::DT_TE_DBL) *in_words = *out_words = 0;
   if (curve != 0 && op == msm::DT_TE_ADD_QUAD) *in_words = *out_words = 0;
@@ -107,7 +188,10 @@ int msm_devtest_run(int curve, int op, const uint32_t* in, uint32_t* out, size_t
   if (e == hipSuccess) e = hipMalloc(&d_out, n * ow * 4);
   if (e == hipSuccess) e = hipMemcpy(d_in, in, n * iw * 4, hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemset(d_out, 0xEE, n * ow * 4);
-  if (e == hipSuccess) {
+  if (e == hipSuccess && op >= msm::DT_PAIR) {
+    e = curve == 2 ? msm::launch_pair_op<msm::Bls12_377_G2>(op - msm::DT_PAIR, d_in, iw, d_out, ow, (uint32_t)n)
+                   : msm::launch_pair_op<msm::Bls12_381_G2>(op - msm::DT_PAIR, d_in, iw, d_out, ow, (uint32_t)n);
+  } else if (e == hipSuccess) {
     switch (curve) {
       case 0: e = msm::launch_op<msm::Bls12_377_G1, true>(op, d_in, iw, d_out, ow, (uint32_t)n); break;
       case 1: e = msm::launch_op<msm::Bls12_381_G1, false>(op, d_in, iw, d_out, ow, (uint32_t)n); break;

@@ -34,7 +34,8 @@ enum DevtestOp : int {
   DT_ADD_QUAD = 18,     // as DT_ADD, four lanes per record (device only)
   DT_TE_ADD_QUAD = 19,  // as DT_TE_ADD, four lanes per record (device only)
   DT_FE_WEAK_REDUCE = 20,    // in a (limbs < 2^31, value < 32p)  out Fe
-  DT_COUNT = 21
+  DT_COUNT = 21,
+  DT_PAIR = 64          // + a G2 op in [DT_EL_MUL, DT_DBL]: the same records with two lanes per record (fp2pair.hpp; device only)
 };
 
 // words of one input / output record of `op` for coordinate elements of EW words (14 for Fp, 28 for Fp2); 0 = unknown op

@@ -16,22 +16,39 @@ struct Launch {
   using El = typename E::T;
   static hipError_t convert_bases(const uint8_t* in, size_t stride, uint32_t n, bool serialized, AffineDevT<El>* out, uint8_t* inf,
                                   hipStream_t st);
+  // `paired` (G2 only, ignored over Fp; per context, option "g2_paired"): the throughput kernels run with every Fp2 value spread over
+  // two neighbouring lanes (LaunchPair below, fp2pair.hpp) -- same records in memory, so the forms mix freely
   static hipError_t accumulate(const uint2* entries, const uint32_t* n_real, uint32_t K,
-                               const AffineDevT<El>* bases, SegOutT<El> out, uint32_t nlanes, hipStream_t st);
+                               const AffineDevT<El>* bases, SegOutT<El> out, uint32_t nlanes, hipStream_t st, bool paired = false);
   // `quad_limit` (per context, option "quad_limit"): launches of at most that many additions use the four-lanes-per-addition
   // kernels (latency), larger ones one lane each (throughput)
   static hipError_t segreduce(const XyzzDevT<El>* in_slots, const uint32_t* in_keys, uint32_t n_in, uint32_t K, SegOutT<El> out,
-                              uint32_t nlanes, uint32_t quad_limit, hipStream_t st);
+                              uint32_t nlanes, uint32_t quad_limit, hipStream_t st, bool paired = false);
   static hipError_t pre_double(const AffineDevT<El>* in, const uint8_t* inf_in, uint32_t n, uint32_t c, XyzzDevT<El>* out, hipStream_t st);
   static hipError_t pre_normalize(const XyzzDevT<El>* in, uint32_t n, uint32_t J, El* prefix, AffineDevT<El>* out, uint8_t* inf_out,
                                   hipStream_t st);
   static hipError_t bucket_reduce(bool first, const XyzzDevT<El>* in_a, const XyzzDevT<El>* in_x, uint32_t n_per_win, uint32_t L,
-                                  uint32_t chunks, uint32_t windows, uint32_t out_stride, XyzzDevT<El>* out_a, XyzzDevT<El>* out_x, hipStream_t st);
+                                  uint32_t chunks, uint32_t windows, uint32_t out_stride, XyzzDevT<El>* out_a, XyzzDevT<El>* out_x, hipStream_t st,
+                                  bool paired = false);
   // small windows: one step of the scan-based reduction (k_reduce_scan_step)
   static hipError_t reduce_scan_step(const XyzzDevT<El>* in, const XyzzDevT<El>* in2, XyzzDevT<El>* out, uint32_t nb, uint32_t windows, uint32_t d, uint32_t mode,
-                                     uint32_t quad_limit, hipStream_t st);
+                                     uint32_t quad_limit, hipStream_t st, bool paired = false);
   // carried buckets: total[b] += part[b] (k_bucket_merge)
-  static hipError_t bucket_merge(XyzzDevT<El>* total, const XyzzDevT<El>* part, uint32_t n, hipStream_t st);
+  static hipError_t bucket_merge(XyzzDevT<El>* total, const XyzzDevT<El>* part, uint32_t n, hipStream_t st, bool paired = false);
+};
+
+// The throughput kernels of a G2 curve with two lanes per point (SwPairLaw, laws.hpp); kernels_<curve>p.hip.  E = Fp2El<F, NB>.
+template <class E>
+struct LaunchPair {
+  static hipError_t accumulate(const uint2* entries, const uint32_t* n_real, uint32_t K, const AffineDevT<Fe2>* bases, SegOutT<Fe2> out, uint32_t nlanes,
+                               hipStream_t st);
+  static hipError_t segreduce(const XyzzDevT<Fe2>* in_slots, const uint32_t* in_keys, uint32_t n_in, uint32_t K, SegOutT<Fe2> out, uint32_t nlanes,
+                              hipStream_t st);
+  static hipError_t bucket_reduce(bool first, const XyzzDevT<Fe2>* in_a, const XyzzDevT<Fe2>* in_x, uint32_t n_per_win, uint32_t L, uint32_t chunks,
+                                  uint32_t windows, uint32_t out_stride, XyzzDevT<Fe2>* out_a, XyzzDevT<Fe2>* out_x, hipStream_t st);
+  static hipError_t reduce_scan_step(const XyzzDevT<Fe2>* in, const XyzzDevT<Fe2>* in2, XyzzDevT<Fe2>* out, uint32_t nb, uint32_t windows, uint32_t d,
+                                     uint32_t mode, hipStream_t st);
+  static hipError_t bucket_merge(XyzzDevT<Fe2>* total, const XyzzDevT<Fe2>* part, uint32_t n, hipStream_t st);
 };
 
 // The twisted-Edwards fast path of BLS12-377 G1 (kernels_377te.hip).  `flags`: [0] += bases without an image (convert),
@@ -66,5 +83,7 @@ extern template struct Launch<Bls12_377_G1::E>;
 extern template struct Launch<Bls12_381_G1::E>;
 extern template struct Launch<Bls12_377_G2::E>;
 extern template struct Launch<Bls12_381_G2::E>;
+extern template struct LaunchPair<Bls12_377_G2::E>;
+extern template struct LaunchPair<Bls12_381_G2::E>;
 
 }  // namespace msm

@@ -9,6 +9,11 @@ namespace msm {
 inline uint32_t launch_blocks(uint64_t n) { return (uint32_t)((n + 255) / 256); }
 
 template <class E>
+struct IsFp2 : std::false_type {};
+template <class F, int NB>
+struct IsFp2<Fp2El<F, NB>> : std::true_type {};
+
+template <class E>
 hipError_t Launch<E>::convert_bases(const uint8_t* in, size_t stride, uint32_t n, bool serialized, AffineDevT<El>* out, uint8_t* inf,
                                     hipStream_t st) {
   if (serialized)
@@ -20,7 +25,10 @@ hipError_t Launch<E>::convert_bases(const uint8_t* in, size_t stride, uint32_t n
 
 template <class E>
 hipError_t Launch<E>::accumulate(const uint2* entries, const uint32_t* n_real, uint32_t K,
-                                 const AffineDevT<El>* bases, SegOutT<El> out, uint32_t nlanes, hipStream_t st) {
+                                 const AffineDevT<El>* bases, SegOutT<El> out, uint32_t nlanes, hipStream_t st, bool paired) {
+  if constexpr (IsFp2<E>::value) {
+    if (paired) return LaunchPair<E>::accumulate(entries, n_real, K, bases, out, nlanes, st);
+  }
   // MSM_GATHER = 0 builds the one-lane-per-record walk instead (A/B: profiles/r02_ab_gather.txt)
 #ifndef MSM_GATHER
 #define MSM_GATHER 2
@@ -36,11 +44,14 @@ hipError_t Launch<E>::accumulate(const uint2* entries, const uint32_t* n_real, u
 
 template <class E>
 hipError_t Launch<E>::segreduce(const XyzzDevT<El>* in_slots, const uint32_t* in_keys, uint32_t n_in, uint32_t K, SegOutT<El> out,
-                                uint32_t nlanes, uint32_t quad_limit, hipStream_t st) {
+                                uint32_t nlanes, uint32_t quad_limit, hipStream_t st, bool paired) {
   if (nlanes <= quad_limit) {   // latency form: four lanes per addition (msm_kernels.hpp)
     hipLaunchKernelGGL((k_segreduce_quad<SwQuad<E>>), dim3(launch_blocks(4ull * nlanes)), dim3(256), 0, st, in_slots, in_keys, n_in, K, out, nlanes,
                        (uint32_t*)nullptr);
     return hipGetLastError();
+  }
+  if constexpr (IsFp2<E>::value) {
+    if (paired) return LaunchPair<E>::segreduce(in_slots, in_keys, n_in, K, out, nlanes, st);
   }
   hipLaunchKernelGGL((k_segreduce<SwLaw<E>>), dim3(launch_blocks(nlanes)), dim3(256), 0, st, in_slots, in_keys, n_in, K, out, nlanes, (uint32_t*)nullptr);
   return hipGetLastError();
@@ -48,7 +59,11 @@ hipError_t Launch<E>::segreduce(const XyzzDevT<El>* in_slots, const uint32_t* in
 
 template <class E>
 hipError_t Launch<E>::bucket_reduce(bool first, const XyzzDevT<El>* in_a, const XyzzDevT<El>* in_x, uint32_t n_per_win, uint32_t L,
-                                    uint32_t chunks, uint32_t windows, uint32_t out_stride, XyzzDevT<El>* out_a, XyzzDevT<El>* out_x, hipStream_t st) {
+                                    uint32_t chunks, uint32_t windows, uint32_t out_stride, XyzzDevT<El>* out_a, XyzzDevT<El>* out_x, hipStream_t st,
+                                    bool paired) {
+  if constexpr (IsFp2<E>::value) {
+    if (paired) return LaunchPair<E>::bucket_reduce(first, in_a, in_x, n_per_win, L, chunks, windows, out_stride, out_a, out_x, st);
+  }
   dim3 grid(launch_blocks((uint64_t)windows * chunks));
   if (first)
     hipLaunchKernelGGL((k_bucket_reduce<SwLaw<E>, true>), grid, dim3(256), 0, st, in_a, in_x, n_per_win, L, chunks, windows, out_stride, out_a, out_x,
@@ -61,19 +76,25 @@ hipError_t Launch<E>::bucket_reduce(bool first, const XyzzDevT<El>* in_a, const 
 
 template <class E>
 hipError_t Launch<E>::reduce_scan_step(const XyzzDevT<El>* in, const XyzzDevT<El>* in2, XyzzDevT<El>* out, uint32_t nb, uint32_t windows, uint32_t d, uint32_t mode,
-                                       uint32_t quad_limit, hipStream_t st) {
+                                       uint32_t quad_limit, hipStream_t st, bool paired) {
   const uint64_t threads = (uint64_t)windows * (mode == 1 ? d : nb);
   if (threads <= quad_limit) {
     hipLaunchKernelGGL((k_reduce_scan_step_quad<SwQuad<E>>), dim3(launch_blocks(4 * threads)), dim3(256), 0, st, in, in2, out, nb, windows, d, mode,
                        (uint32_t*)nullptr);
     return hipGetLastError();
   }
+  if constexpr (IsFp2<E>::value) {
+    if (paired) return LaunchPair<E>::reduce_scan_step(in, in2, out, nb, windows, d, mode, st);
+  }
   hipLaunchKernelGGL((k_reduce_scan_step<SwLaw<E>>), dim3(launch_blocks(threads)), dim3(256), 0, st, in, in2, out, nb, windows, d, mode, (uint32_t*)nullptr);
   return hipGetLastError();
 }
 
 template <class E>
-hipError_t Launch<E>::bucket_merge(XyzzDevT<El>* total, const XyzzDevT<El>* part, uint32_t n, hipStream_t st) {
+hipError_t Launch<E>::bucket_merge(XyzzDevT<El>* total, const XyzzDevT<El>* part, uint32_t n, hipStream_t st, bool paired) {
+  if constexpr (IsFp2<E>::value) {
+    if (paired) return LaunchPair<E>::bucket_merge(total, part, n, st);
+  }
   hipLaunchKernelGGL((k_bucket_merge<SwLaw<E>>), dim3(launch_blocks(n)), dim3(256), 0, st, total, part, n, (uint32_t*)nullptr);
   return hipGetLastError();
 }

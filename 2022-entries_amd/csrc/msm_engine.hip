@@ -207,6 +207,11 @@ struct Plan {
 
 }  // namespace
 
+#ifndef MSM_G2_PAIRED_DEFAULT
+#define MSM_G2_PAIRED_DEFAULT 31
+#endif
+constexpr long kDefaultG2Paired = MSM_G2_PAIRED_DEFAULT;
+
 struct RcclState;   // the dlopen'ed RCCL entry points and one communicator per shard (sharded contexts only)
 
 struct mi355_msm_ctx {
@@ -233,6 +238,7 @@ struct mi355_msm_ctx {
   long opt_assume_subgroup = 0;   // 1: every base is in the order-r subgroup (r P = O), so a scalar k in (r/2, r) may run as (r - k)(-P)
   long opt_reduce_log_chunk = 0, opt_reduce_log_chunk0 = 0;
   long opt_reduce_scan = -1;      // 0: recursive chunked running sums only; otherwise the scan tail (default)
+  long opt_reduce_fill = 0;       // waves per SIMD the first chunked level of the bucket reduction is cut for (0 = the default, 1)
   long opt_twisted_edwards = 1;   // BLS12-377 G1 only: accumulate on the twisted-Edwards image when every base has one
   // twisted-Edwards fast path (te.hpp): records for every table level; te_active is decided per base set
   DevBuf te_bases, flags;         // flags: u32[2] on the device, [0] bases without an image, [1] an addition failed
@@ -251,6 +257,9 @@ struct mi355_msm_ctx {
   long opt_mem_limit = 0;         // test hook: pretend the device has at most this many free bytes when sizing chunks
   long inject_alloc_failures = 0; // test hook: the next N work-buffer reservations of THIS context fail as if HBM were exhausted (-K: only the K-th from now)
   uint32_t quad_limit = LaunchTe::kDefaultQuadLimit;   // merge / scan launches of at most this many additions run four lanes per addition
+  // G2 only (option "g2_paired"): which throughput kernels run with every Fp2 value spread over two lanes (fp2pair.hpp) --
+  // bit 0 accumulate, 1 first level of the bucket reduction, 2 fragment merge, 3 scan steps, 4 bucket merge of carried batches
+  long opt_g2_paired = kDefaultG2Paired;
   // sharded context (mi355_msm_create_sharded): this object then owns no device state itself, only the per-device children
   std::vector<mi355_msm_ctx*> shards;
   std::vector<size_t> shard_lo;   // bases [shard_lo[g], shard_lo[g+1]) live on shard g
@@ -325,16 +334,19 @@ struct mi355_msm_ctx {
       // The first level is one wave per SIMD (an accumulator chain per lane, 53 K lanes): 13 windows x 4096 chunks are 832 waves on
       // the 1024 SIMDs of an MI355X -- a fifth of the chip idles while every lane walks 128 buckets.  Cut the window into as many
       // chunks as fill the SIMDs once (4994 chunks of 105 buckets = 1015 waves) and let the scan run on the next power of two.
+      // `reduce_fill` (option, default 1) asks for that many waves per SIMD instead: two waves issue a VALU instruction per ~4.1 cycles
+      // where a lone wave issues one per ~5.3, at the price of a scan over twice the elements.
       const uint64_t kSimds = 1024;   // 256 CUs x 4 (the plan is also computed without a device: mi355_msm_plan)
+      const uint64_t fill = opt_reduce_fill > 0 ? (uint64_t)opt_reduce_fill : 1;
       const uint64_t waves = ((uint64_t)p.bucket_windows * p.T0 + 63) / 64;
-      if (waves < kSimds && p.T0 >= 1024) {
-        const uint32_t t_fit = (uint32_t)(kSimds * 64 / p.bucket_windows);
-        if (t_fit > p.T0 && t_fit < 2 * p.T0) {
+      if (waves < fill * kSimds && p.T0 >= 1024) {
+        const uint32_t t_fit = (uint32_t)(fill * kSimds * 64 / p.bucket_windows);
+        if (t_fit > p.T0 && t_fit < 2 * fill * p.T0) {
           const uint32_t L = ceil_div(p.half, t_fit);
           if (L >= 8 && L < p.L0) {
             p.L0 = L;
             p.T0 = ceil_div(p.half, L);
-            p.scan_nb = 2 * p.scan_nb;   // T0 < 2 x the old power of two
+            while (p.scan_nb < p.T0) p.scan_nb *= 2;   // the scan runs on the next power of two, the tail of a row stays empty
           }
         }
       }
@@ -752,7 +764,7 @@ bool run_chunk_impl(mi355_msm_ctx* ctx, const uint32_t* d_scalars, size_t base0,
   if constexpr (TE)
     HIP_OK(LaunchTe::accumulate(entries, n_real, p.K, ctx->te_bases.as<TeAffineDev>(), so, p.nlanes, flags, st));
   else
-    HIP_OK(Launch<E>::accumulate(entries, n_real, p.K, bases, so, p.nlanes, st));
+    HIP_OK(Launch<E>::accumulate(entries, n_real, p.K, bases, so, p.nlanes, st, (ctx->opt_g2_paired & 1) != 0));
   HIP_OK(hipEventRecord(ev[3], st));
 #ifdef MSM_DEBUG
   {
@@ -774,7 +786,8 @@ bool run_chunk_impl(mi355_msm_ctx* ctx, const uint32_t* d_scalars, size_t base0,
       if constexpr (TE)
         HIP_OK(LaunchTe::segreduce(ctx->slots[cur].as<XyzzDev>(), ctx->slot_keys[cur].as<uint32_t>(), n_in, p.segK, o, nl, ctx->quad_limit, flags, st));
       else
-        HIP_OK(Launch<E>::segreduce(ctx->slots[cur].as<XyzzDev>(), ctx->slot_keys[cur].as<uint32_t>(), n_in, p.segK, o, nl, ctx->quad_limit, st));
+        HIP_OK(Launch<E>::segreduce(ctx->slots[cur].as<XyzzDev>(), ctx->slot_keys[cur].as<uint32_t>(), n_in, p.segK, o, nl, ctx->quad_limit, st,
+                                    (ctx->opt_g2_paired & 4) != 0));
       if (nl == 1) break;
       n_in = 2 * nl;
       cur ^= 1;
@@ -789,7 +802,7 @@ bool run_chunk_impl(mi355_msm_ctx* ctx, const uint32_t* d_scalars, size_t base0,
       if constexpr (TE)
         HIP_OK(LaunchTe::bucket_merge(ctx->carry_buckets.as<XyzzDev>(), ctx->buckets.as<XyzzDev>(), (uint32_t)nbuckets, flags, st));
       else
-        HIP_OK(Launch<E>::bucket_merge(ctx->carry_buckets.as<XyzzDev>(), ctx->buckets.as<XyzzDev>(), (uint32_t)nbuckets, st));
+        HIP_OK(Launch<E>::bucket_merge(ctx->carry_buckets.as<XyzzDev>(), ctx->buckets.as<XyzzDev>(), (uint32_t)nbuckets, st, (ctx->opt_g2_paired & 16) != 0));
     }
     bucket_src = ctx->carry_buckets.as<XyzzDev>();
   }
@@ -831,7 +844,7 @@ bool run_chunk_impl(mi355_msm_ctx* ctx, const uint32_t* d_scalars, size_t base0,
                                        ctx->red_a[0].as<XyzzDev>(), ctx->red_x[0].as<XyzzDev>(), flags, st));
       else
         HIP_OK(Launch<E>::bucket_reduce(true, nullptr, bucket_src, p.half, p.L0, p.T0, p.bucket_windows, p.scan_nb,
-                                        ctx->red_a[0].as<XyzzDev>(), ctx->red_x[0].as<XyzzDev>(), st));
+                                        ctx->red_a[0].as<XyzzDev>(), ctx->red_x[0].as<XyzzDev>(), st, (ctx->opt_g2_paired & 2) != 0));
       nb = p.scan_nb;
       a_sums = ctx->red_a[0].as<XyzzDev>();
       bufs[0] = ctx->red_x[0].as<XyzzDev>();
@@ -842,7 +855,7 @@ bool run_chunk_impl(mi355_msm_ctx* ctx, const uint32_t* d_scalars, size_t base0,
       if constexpr (TE)
         HIP_OK(LaunchTe::reduce_scan_step(bufs[cur], a_sums, bufs[cur ^ 1], nb, p.bucket_windows, d, mode, ctx->quad_limit, flags, st));
       else
-        HIP_OK(Launch<E>::reduce_scan_step(bufs[cur], a_sums, bufs[cur ^ 1], nb, p.bucket_windows, d, mode, ctx->quad_limit, st));
+        HIP_OK(Launch<E>::reduce_scan_step(bufs[cur], a_sums, bufs[cur ^ 1], nb, p.bucket_windows, d, mode, ctx->quad_limit, st, (ctx->opt_g2_paired & 8) != 0));
       cur ^= 1;
     };
     for (uint32_t d = 1; d < nb; d <<= 1) step(d, 0);
@@ -862,7 +875,7 @@ bool run_chunk_impl(mi355_msm_ctx* ctx, const uint32_t* d_scalars, size_t base0,
                                      ctx->red_a[0].as<XyzzDev>(), ctx->red_x[0].as<XyzzDev>(), flags, st));
     else
       HIP_OK(Launch<E>::bucket_reduce(true, nullptr, bucket_src, n_per_win, 1u << logL, chunks, p.bucket_windows, chunks,
-                                      ctx->red_a[0].as<XyzzDev>(), ctx->red_x[0].as<XyzzDev>(), st));
+                                      ctx->red_a[0].as<XyzzDev>(), ctx->red_x[0].as<XyzzDev>(), st, (ctx->opt_g2_paired & 2) != 0));
     while (chunks > 1) {
       n_per_win = chunks;
       logL = p.logL;
@@ -872,7 +885,7 @@ bool run_chunk_impl(mi355_msm_ctx* ctx, const uint32_t* d_scalars, size_t base0,
                                        p.bucket_windows, chunks, ctx->red_a[rb ^ 1].as<XyzzDev>(), ctx->red_x[rb ^ 1].as<XyzzDev>(), flags, st));
       else
         HIP_OK(Launch<E>::bucket_reduce(false, ctx->red_a[rb].as<XyzzDev>(), ctx->red_x[rb].as<XyzzDev>(), n_per_win, 1u << logL, chunks,
-                                        p.bucket_windows, chunks, ctx->red_a[rb ^ 1].as<XyzzDev>(), ctx->red_x[rb ^ 1].as<XyzzDev>(), st));
+                                        p.bucket_windows, chunks, ctx->red_a[rb ^ 1].as<XyzzDev>(), ctx->red_x[rb ^ 1].as<XyzzDev>(), st, (ctx->opt_g2_paired & 2) != 0));
       rb ^= 1;
     }
     HIP_OK(hipEventRecord(ev[5], st));
@@ -1410,9 +1423,16 @@ RustError mi355_msm_set_option(mi355_msm_ctx* ctx, const char* key, long value) 
       // launches of at most this many additions run four lanes per addition (merge / scan steps); a field of THIS context
       if (value < 0 || value > (1L << 24)) bad_arg("quad_limit %ld out of range [0, 2^24]", value);
       ctx->quad_limit = (uint32_t)value;
+    } else if (k == "g2_paired") {
+      // G2 contexts: bit mask of the throughput kernels that run two lanes per point (ignored on G1)
+      if (value < 0 || value > 31) bad_arg("g2_paired %ld out of range [0, 31]", value);
+      ctx->opt_g2_paired = value;
     } else if (k == "reduce_scan") {
       if (value < -1 || value > 1) bad_arg("reduce_scan %ld out of range [-1, 1]", value);
       ctx->opt_reduce_scan = value;
+    } else if (k == "reduce_fill") {
+      if (value < 0 || value > 4) bad_arg("reduce_fill %ld out of range [0, 4]", value);
+      ctx->opt_reduce_fill = value;
     } else if (k == "reduce_log_chunk0") {
       if (value < 0 || value > 7) bad_arg("reduce_log_chunk0 %ld out of range [1, 7]", value);
       ctx->opt_reduce_log_chunk0 = value;

@@ -72,20 +72,18 @@ __global__ void __launch_bounds__(256) k_convert_bases(const uint8_t* __restrict
 // ------------------------------------------------------------------------------------------------
 // Where a finished run fragment goes.  A fragment is the lane's partial sum for one key.  It is the
 // whole bucket only if the run cannot continue into a neighbouring lane.
-template <class T>
-__device__ __forceinline__ void seg_flush(const SegOutT<T>& o, uint32_t t, uint32_t nlanes, uint32_t key, const XyzzT<T>& acc,
-                                          bool is_first, bool is_last) {
+// `half`: which half of every Fp2 coordinate this lane holds when a point is spread over two lanes (G::LANES = 2, fp2pair.hpp);
+// both lanes of such a pair walk the same entries, so everything but the stored limbs is pair-uniform.
+template <class G>
+__device__ __forceinline__ void seg_flush(const SegOutT<typename G::MemT>& o, uint32_t t, uint32_t nlanes, uint32_t key,
+                                          const XyzzT<typename G::T>& acc, bool is_first, bool is_last, uint32_t half = 0) {
   const bool complete = (!is_first || t == 0) && (!is_last || t == nlanes - 1);
-  XyzzDevT<T> v;
-  v.p = acc;
   if (complete) {
-    o.buckets[key] = v;
-  } else if (is_first) {
-    o.slots[2 * (size_t)t] = v;
-    o.slot_keys[2 * (size_t)t] = key;
+    G::store_pt(o.buckets + key, acc, half);
   } else {
-    o.slots[2 * (size_t)t + 1] = v;
-    o.slot_keys[2 * (size_t)t + 1] = key;
+    const size_t s = 2 * (size_t)t + (is_first ? 0 : 1);
+    G::store_pt(o.slots + s, acc, half);
+    o.slot_keys[s] = key;
   }
 }
 
@@ -97,6 +95,7 @@ __global__ void __launch_bounds__(256, G::ACC_WAVES) k_accumulate(const uint2* _
                                                     uint32_t K, const typename G::BaseDev* __restrict__ bases,
                                                     SegOutT<typename G::T> out, uint32_t nlanes, uint32_t* __restrict__ flags) {
   using E = typename G::E;
+  static_assert(G::LANES == 1, "the one-lane-per-record walk has no paired form");
   const uint32_t t = blockIdx.x * 256 + threadIdx.x;
   if (t >= nlanes) return;
   typename E::Md md;
@@ -132,7 +131,7 @@ __global__ void __launch_bounds__(256, G::ACC_WAVES) k_accumulate(const uint2* _
     if (end - e > 2) ent_n = entries[e + 2];
     if (key != cur) {
       if (cur != KEY_NONE) {
-        seg_flush(out, t, nlanes, cur, acc, first, false);
+        seg_flush<G>(out, t, nlanes, cur, acc, first, false);
         first = false;
       }
       cur = key;
@@ -143,7 +142,7 @@ __global__ void __launch_bounds__(256, G::ACC_WAVES) k_accumulate(const uint2* _
     if (G::CHECKS) bad |= G::failed(acc);
     fresh = false;
   }
-  if (cur != KEY_NONE) seg_flush(out, t, nlanes, cur, acc, first, true);
+  if (cur != KEY_NONE) seg_flush<G>(out, t, nlanes, cur, acc, first, true);
   if (G::CHECKS && bad) flags[1] = 1;
 }
 
@@ -167,9 +166,12 @@ typedef const __attribute__((address_space(1))) void* msm_gbl_ptr_t;
 template <class G>
 __global__ void __launch_bounds__(256, G::ACC_WAVES) k_accumulate_glds(const uint2* __restrict__ entries, const uint32_t* __restrict__ n_real,
                                                          uint32_t K, const typename G::BaseDev* __restrict__ bases,
-                                                         SegOutT<typename G::T> out, uint32_t nlanes, uint32_t* __restrict__ flags) {
+                                                         SegOutT<typename G::MemT> out, uint32_t nlanes, uint32_t* __restrict__ flags) {
   using E = typename G::E;
   using Base = typename G::Base;
+  // LANES = 2 (SwPairLaw, fp2pair.hpp): walking lane t is the PAIR of hardware lanes 2t, 2t + 1, each holding one half of every Fp2
+  // value; both run the code below on the same entries.  A quad then gathers RPQ = 2 records per iteration instead of 4.
+  constexpr int LANES = G::LANES, RPQ = 4 / LANES;
   constexpr int SECT = G::GATHER_SECTORS;                  // 64-B sectors per record
   constexpr int RS = 1024;                                 // bytes of one (record index, sector) region: 64 lanes x 16 B
 #ifndef MSM_ACC_LDS_PAD
@@ -184,15 +186,15 @@ __global__ void __launch_bounds__(256, G::ACC_WAVES) k_accumulate_glds(const uin
 #ifndef MSM_ACC_PRIO
 #define MSM_ACC_PRIO 0      // A/B only (profiles/r03_ab_setprio.txt): 1 = s_setprio 2 around the addition (a wave in its MAD-dense
 #endif                      // phase runs ahead of the waves that gather), 2 = around the gather phase, 3 = odd waves start late
-  constexpr int WAVE_LDS = 4 * SECT * RS + 256 + MSM_ACC_LDS_PAD;
+  constexpr int WAVE_LDS = RPQ * SECT * RS + 256 + MSM_ACC_LDS_PAD;
   static_assert(sizeof(typename G::BaseDev) % 64 == 0 && SECT >= 2 && SECT <= 4 && SECT * 64 <= (int)sizeof(typename G::BaseDev), "record layout");
   __shared__ __attribute__((aligned(16))) unsigned char lds[4 * WAVE_LDS];
-  const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+  const uint32_t t = (blockIdx.x * 256 + threadIdx.x) / LANES, half = threadIdx.x % LANES;
   const uint32_t lane = threadIdx.x & 63, sub = lane & 3, quad = lane >> 2;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   unsigned char* wave_lds = lds + wave * WAVE_LDS;
-  // my record: index `sub` within my quad; its sector c starts at rec + c * RS
-  const unsigned char* rec = wave_lds + sub * (SECT * RS + 64) + quad * 64;
+  // my record: index `sub / LANES` within my quad; its sector c starts at rec + c * RS
+  const unsigned char* rec = wave_lds + (sub / LANES) * (SECT * RS + 64) + quad * 64;
   typename E::Md md;
   const bool lane_ok = t < nlanes;
   if (lane_ok) {
@@ -265,10 +267,15 @@ __global__ void __launch_bounds__(256, G::ACC_WAVES) k_accumulate_glds(const uin
 #define MSM_GLDS_ISSUE(val, valid)                                \
   do {                                                            \
     const int mine_ = (valid) ? (int)((((val) & IDX_MASK & MSM_ACC_IDX_AND)) << MSM_ACC_IDX_SHL) : 0; \
-    MSM_GLDS_ONE(0, 0x00);                                        \
-    MSM_GLDS_ONE(1, 0x55);                                        \
-    MSM_GLDS_ONE(2, 0xaa);                                        \
-    MSM_GLDS_ONE(3, 0xff);                                        \
+    if constexpr (LANES == 1) {                                   \
+      MSM_GLDS_ONE(0, 0x00);                                      \
+      MSM_GLDS_ONE(1, 0x55);                                      \
+      MSM_GLDS_ONE(2, 0xaa);                                      \
+      MSM_GLDS_ONE(3, 0xff);                                      \
+    } else {   /* the records of the quad's two pairs: lanes 0 and 2 name them */ \
+      MSM_GLDS_ONE(0, 0x00);                                      \
+      MSM_GLDS_ONE(1, 0xaa);                                      \
+    }                                                             \
   } while (0)
 
   MSM_GLDS_ISSUE(val_c, alive);
@@ -282,7 +289,7 @@ __global__ void __launch_bounds__(256, G::ACC_WAVES) k_accumulate_glds(const uin
   uint32_t trips = K;
   if constexpr (G::ITER_BARRIER) {
     // block-uniform trip count: the block's first lane has the most entries (a lane's share is min(K, n_entries - beg))
-    const uint64_t b0 = (uint64_t)blockIdx.x * 256 * K;
+    const uint64_t b0 = (uint64_t)blockIdx.x * (256 / LANES) * K;
     trips = b0 < n_entries ? (uint32_t)((n_entries - b0 < K) ? n_entries - b0 : K) : 0;
   }
   for (uint32_t k = 0; k < trips; k++) {
@@ -296,7 +303,7 @@ __global__ void __launch_bounds__(256, G::ACC_WAVES) k_accumulate_glds(const uin
 #endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the DMA of this entry's records has landed
     __builtin_amdgcn_wave_barrier();
-    G::load_sectors(p, rec, RS, alive && (val_c >> 31) != 0);
+    G::load_sectors(p, rec, RS, alive && (val_c >> 31) != 0, half);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // ... and has been read, before the next DMA overwrites it
     __builtin_amdgcn_wave_barrier();
     const uint32_t key = key_c, val = val_c, e = beg + k;
@@ -326,7 +333,7 @@ __global__ void __launch_bounds__(256, G::ACC_WAVES) k_accumulate_glds(const uin
     if (add_now) {
       if (key != cur) {
         if (cur != KEY_NONE) {
-          seg_flush(out, t, nlanes, cur, acc, first, false);
+          seg_flush<G>(out, t, nlanes, cur, acc, first, false, half);
           first = false;
         }
         cur = key;
@@ -338,7 +345,7 @@ __global__ void __launch_bounds__(256, G::ACC_WAVES) k_accumulate_glds(const uin
 #endif
       if (G::madd_loaded(acc, p, (val >> 31) != 0, fresh, md)) {
         // exceptional pair (short Weierstrass only): the record in LDS is already being overwritten, so fetch it again
-        const Base again = G::from_dev(bases[val & IDX_MASK]);
+        const Base again = G::from_dev_lane(bases[val & IDX_MASK], half);
         G::madd_same_x(acc, again, (val >> 31) != 0, md);
       }
 #if MSM_ACC_PRIO == 1
@@ -348,7 +355,7 @@ __global__ void __launch_bounds__(256, G::ACC_WAVES) k_accumulate_glds(const uin
       fresh = false;
     }
   }
-  if (cur != KEY_NONE) seg_flush(out, t, nlanes, cur, acc, first, true);
+  if (cur != KEY_NONE) seg_flush<G>(out, t, nlanes, cur, acc, first, true, half);
   if (G::CHECKS && bad) flags[1] = 1;
 #undef MSM_GLDS_ISSUE
 #undef MSM_GLDS_ONE
@@ -359,11 +366,11 @@ __global__ void __launch_bounds__(256, G::ACC_WAVES) k_accumulate_glds(const uin
 // Merge run fragments: same walk over the slot sequence of the previous level (keys non-decreasing,
 // KEY_NONE = hole), full additions.  Recursion ends when one lane covers everything.
 template <class G>
-__global__ void __launch_bounds__(256) k_segreduce(const XyzzDevT<typename G::T>* __restrict__ in_slots,
+__global__ void __launch_bounds__(256) k_segreduce(const XyzzDevT<typename G::MemT>* __restrict__ in_slots,
                                                    const uint32_t* __restrict__ in_keys, uint32_t n_in, uint32_t K,
-                                                   SegOutT<typename G::T> out, uint32_t nlanes, uint32_t* __restrict__ flags) {
+                                                   SegOutT<typename G::MemT> out, uint32_t nlanes, uint32_t* __restrict__ flags) {
   using E = typename G::E;
-  const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+  const uint32_t t = (blockIdx.x * 256 + threadIdx.x) / G::LANES, half = threadIdx.x % G::LANES;
   if (t >= nlanes) return;
   typename E::Md md;
   out.slot_keys[2 * (size_t)t] = KEY_NONE;
@@ -377,20 +384,20 @@ __global__ void __launch_bounds__(256) k_segreduce(const XyzzDevT<typename G::T>
   for (uint64_t e = beg; e < end; e++) {
     const uint32_t key = in_keys[e];
     if (key == KEY_NONE) continue;
-    const XyzzDevT<typename G::T> v = in_slots[e];
+    const XyzzT<typename G::T> v = G::load_pt(in_slots + e, half);
     if (key != cur) {
       if (cur != KEY_NONE) {
-        seg_flush(out, t, nlanes, cur, acc, first, false);
+        seg_flush<G>(out, t, nlanes, cur, acc, first, false, half);
         first = false;
       }
       cur = key;
-      acc = v.p;
+      acc = v;
     } else {
-      G::add(acc, v.p, md);
+      G::add(acc, v, md);
       if (G::CHECKS) bad |= G::failed(acc);
     }
   }
-  if (cur != KEY_NONE) seg_flush(out, t, nlanes, cur, acc, first, true);
+  if (cur != KEY_NONE) seg_flush<G>(out, t, nlanes, cur, acc, first, true, half);
   if (G::CHECKS && bad) flags[1] = 1;
 }
 
@@ -405,14 +412,14 @@ __global__ void __launch_bounds__(256) k_segreduce(const XyzzDevT<typename G::T>
 // wave each (Plan::L0) -- 13 windows x 4096 chunks of 128 buckets are 832 waves on 1024 SIMDs, 4994 chunks of 105 are 1015; the
 // outputs of window w start at w * out_stride (a power of two for the scan that follows, the tail of a row stays empty).
 template <class G, bool FIRST>
-__global__ void __launch_bounds__(256, G::ACC_WAVES) k_bucket_reduce(const XyzzDevT<typename G::T>* __restrict__ in_a,
-                                                       const XyzzDevT<typename G::T>* __restrict__ in_x,
+__global__ void __launch_bounds__(256, G::ACC_WAVES) k_bucket_reduce(const XyzzDevT<typename G::MemT>* __restrict__ in_a,
+                                                       const XyzzDevT<typename G::MemT>* __restrict__ in_x,
                                                        uint32_t n_per_win, uint32_t L, uint32_t chunks_per_win,
-                                                       uint32_t windows, uint32_t out_stride, XyzzDevT<typename G::T>* __restrict__ out_a,
-                                                       XyzzDevT<typename G::T>* __restrict__ out_x, uint32_t* __restrict__ flags) {
+                                                       uint32_t windows, uint32_t out_stride, XyzzDevT<typename G::MemT>* __restrict__ out_a,
+                                                       XyzzDevT<typename G::MemT>* __restrict__ out_x, uint32_t* __restrict__ flags) {
   using E = typename G::E;
-  using XD = XyzzDevT<typename G::T>;
-  const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+  using XD = XyzzDevT<typename G::MemT>;
+  const uint32_t g = (blockIdx.x * 256 + threadIdx.x) / G::LANES, half = threadIdx.x % G::LANES;
   if (g >= windows * chunks_per_win) return;
   typename E::Md md;
   const uint32_t w = g / chunks_per_win, t = g % chunks_per_win;
@@ -424,8 +431,8 @@ __global__ void __launch_bounds__(256, G::ACC_WAVES) k_bucket_reduce(const XyzzD
   G::set_identity(run);
   G::set_identity(wsum);
   for (uint32_t j = hi; j-- > lo;) {
-    const XD v = x[j];
-    G::add(run, v.p, md);
+    const XyzzT<typename G::T> v = G::load_pt(x + j, half);
+    G::add(run, v, md);
     if (G::CHECKS) bad |= G::failed(run);
     if (FIRST || j > lo) {
       G::add(wsum, run, md);
@@ -435,15 +442,13 @@ __global__ void __launch_bounds__(256, G::ACC_WAVES) k_bucket_reduce(const XyzzD
   if (!FIRST) {
     const XD* a = in_a + (size_t)w * n_per_win;
     for (uint32_t j = lo; j < hi; j++) {
-      const XD v = a[j];
-      G::add(wsum, v.p, md);
+      const XyzzT<typename G::T> v = G::load_pt(a + j, half);
+      G::add(wsum, v, md);
       if (G::CHECKS) bad |= G::failed(wsum);
     }
   }
   const size_t at = (size_t)w * out_stride + t;
-  XD o;
-  o.p = wsum;
-  out_a[at] = o;
+  G::store_pt(out_a + at, wsum, half);
   // X'_t = L * run, most significant bit of L first: doublings, and an addition of the sum itself for every further set bit
   if ((L & (L - 1)) == 0) {
     G::mul_pow2(run, 31 - __builtin_clz(L), md);
@@ -459,8 +464,7 @@ __global__ void __launch_bounds__(256, G::ACC_WAVES) k_bucket_reduce(const XyzzD
       }
     }
   }
-  o.p = run;
-  out_x[at] = o;
+  G::store_pt(out_x + at, run, half);
   if (G::CHECKS && bad) flags[1] = 1;
 }
 
@@ -471,24 +475,23 @@ __global__ void __launch_bounds__(256, G::ACC_WAVES) k_bucket_reduce(const XyzzD
 // instead of a bucket reduction (two per bucket, then the scan tail), a host fold and a stream synchronisation per chunk -- and
 // every chunk can use the window size of the WHOLE batch.
 template <class G>
-__global__ void __launch_bounds__(256, G::ACC_WAVES) k_bucket_merge(XyzzDevT<typename G::T>* __restrict__ total,
-                                                                    const XyzzDevT<typename G::T>* __restrict__ part, uint32_t n,
+__global__ void __launch_bounds__(256, G::ACC_WAVES) k_bucket_merge(XyzzDevT<typename G::MemT>* __restrict__ total,
+                                                                    const XyzzDevT<typename G::MemT>* __restrict__ part, uint32_t n,
                                                                     uint32_t* __restrict__ flags) {
   using E = typename G::E;
-  using XD = XyzzDevT<typename G::T>;
-  const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+  const uint32_t g = (blockIdx.x * 256 + threadIdx.x) / G::LANES, half = threadIdx.x % G::LANES;
   if (g >= n) return;
-  const XD v = part[g];
-  if (G::nothing(v.p)) return;   // the chunk left this bucket empty
-  XD t = total[g];
-  if (G::nothing(t.p)) {
-    total[g] = v;
+  const XyzzT<typename G::T> v = G::load_pt(part + g, half);
+  if (G::nothing(v)) return;   // the chunk left this bucket empty
+  XyzzT<typename G::T> t = G::load_pt(total + g, half);
+  if (G::nothing(t)) {
+    G::store_pt(total + g, v, half);
     return;
   }
   typename E::Md md;
-  G::add(t.p, v.p, md);
-  if (G::CHECKS && G::failed(t.p)) flags[1] = 1;
-  total[g] = t;
+  G::add(t, v, md);
+  if (G::CHECKS && G::failed(t)) flags[1] = 1;
+  G::store_pt(total + g, t, half);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -503,33 +506,31 @@ __global__ void __launch_bounds__(256, G::ACC_WAVES) k_bucket_merge(XyzzDevT<typ
 // V = sum_t A_t + sum_t t X_t), which leaves <= 4096 chunks per window; the scan then runs on the X_t, and
 // mode 2 joins the two sums: out_j = (j == 0 ? identity : S_j) + A_j   (sum_t t X_t = sum_(j >= 1) S_j), a tree finishes.
 template <class G>
-__global__ void __launch_bounds__(256, G::ACC_WAVES) k_reduce_scan_step(const XyzzDevT<typename G::T>* __restrict__ in,
-                                                                        const XyzzDevT<typename G::T>* __restrict__ in2,
-                                                                        XyzzDevT<typename G::T>* __restrict__ out, uint32_t nb, uint32_t windows,
+__global__ void __launch_bounds__(256, G::ACC_WAVES) k_reduce_scan_step(const XyzzDevT<typename G::MemT>* __restrict__ in,
+                                                                        const XyzzDevT<typename G::MemT>* __restrict__ in2,
+                                                                        XyzzDevT<typename G::MemT>* __restrict__ out, uint32_t nb, uint32_t windows,
                                                                         uint32_t d, uint32_t mode, uint32_t* __restrict__ flags) {
   using E = typename G::E;
-  using XD = XyzzDevT<typename G::T>;
+  using XD = XyzzDevT<typename G::MemT>;
   const uint32_t span = mode == 1 ? d : nb;
-  const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+  const uint32_t g = (blockIdx.x * 256 + threadIdx.x) / G::LANES, half = threadIdx.x % G::LANES;
   if (g >= windows * span) return;
   typename E::Md md;
   const uint32_t w = g / span, j = g % span;
   const XD* row = in + (size_t)w * nb;
-  XyzzT<typename G::T> r = row[j].p;
+  XyzzT<typename G::T> r = G::load_pt(row + j, half);
   if (G::is_empty(r) || (mode == 2 && j == 0)) G::set_identity(r);     // (a bucket nobody wrote is all zero)
   bool bad = false;
   if (mode == 2) {
-    const XD v = in2[(size_t)w * nb + j];
-    G::add(r, v.p, md);
+    const XyzzT<typename G::T> v = G::load_pt(in2 + (size_t)w * nb + j, half);
+    G::add(r, v, md);
     if (G::CHECKS) bad = G::failed(r);
   } else if (j + d < nb) {
-    const XD v = row[j + d];
-    G::add(r, v.p, md);
+    const XyzzT<typename G::T> v = G::load_pt(row + j + d, half);
+    G::add(r, v, md);
     if (G::CHECKS) bad = G::failed(r);
   }
-  XD o;
-  o.p = r;
-  out[(size_t)w * nb + j] = o;
+  G::store_pt(out + (size_t)w * nb + j, r, half);
   if (G::CHECKS && bad) flags[1] = 1;
 }
 

@@ -132,6 +132,13 @@ RustError mi355_msm_run_device(mi355_msm_ctx* ctx, void* out_projective, const v
  * "reduce_scan_log" 6..18 = log2 of the elements per window at which the scan takes over (default 12).
  * "quad_limit" (per context, default 2^18): merge / scan launches of at most that many additions spread each
  * addition over four lanes (latency); 0 = always one lane per addition.
+ * "g2_paired" (G2 contexts; bit mask, default 31 = all; ignored on G1): which throughput kernels hold every Fp2 value on TWO
+ * neighbouring lanes (c0 on the even, c1 on the odd one; csrc/fp2pair.hpp) and so run two waves per SIMD instead of one --
+ * bit 0 bucket accumulation, 1 first level of the bucket reduction, 2 fragment merge, 3 scan steps, 4 bucket merge of carried
+ * batches.  Same records in memory, same result bytes; 0 restores the one-lane-per-point kernels (the A/B of
+ * profiles/r05_ab_g2_paired.txt: 2^24 pairs 122 -> 109 ms).
+ * "reduce_fill" 1..4 (default 1): waves per SIMD the first chunked level of the bucket reduction is cut for (measured: 2 does
+ * not pay, profiles/r05_ab_reduce_fill.txt).
  * "assume_subgroup" = 1 (default 0): the caller guarantees that every base lies in the order-r subgroup (r P = O), as the ZPrize
  * generator's do.  A scalar k in (r/2, r) then runs as (r - k)(-P): the winners' top-bit trick (CMB ProcessSignedDigits.cu:10-20,
  * 123-128), one significant bit less, so BLS12-377 scalars tile 12 windows of 21 bits and the auto window size moves from 20 to 21

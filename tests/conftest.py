@@ -14,6 +14,20 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_finish(session):
+    """GPU sessions: let torch bring up ITS HIP runtime before any test dlopens a library linked against /opt/rocm's (the
+    element-wise device tests load libmsm_devtest.so without torch): the other order leaves torch.cuda unavailable for the rest of
+    the process, which made the outcome of a partial run depend on which test file came first."""
+    if any(item.get_closest_marker("gpu") for item in session.items):
+        try:
+            import torch
+
+            if torch.cuda.is_available():
+                torch.cuda.init()
+        except Exception:
+            pass
+
+
 def _ensure_built():
     """CPU-side artefacts (oracle, host test lib, the HIP .so cross-compiled) are built once per session if missing."""
     need = [os.path.join(ROOT, "oracle", "liboracle.so"),

@@ -30,6 +30,7 @@ R392 = 1 << (NL * LB)
 OPS = dict(FE_MUL=0, FE_SQR=1, FE_MUL2=2, NOT_AND_LMASK=3, EL_MUL=4, EL_SQR=5, EL_MUL_C=6, EL_MUL_C_BIG=7, EL_SQR_C=8,
            EL_MUL_SUB_C=9, MADD_COMMON=10, MADD=11, ADD=12, DBL=13, TE_MADD=14, TE_MADD_SWAPPED=15, TE_ADD=16, TE_DBL=17,
            ADD_QUAD=18, TE_ADD_QUAD=19, FE_WEAK_REDUCE=20)
+DT_PAIR = 64
 CURVES = {0: m.BLS12_377_G1, 1: m.BLS12_381_G1, 2: m.BLS12_377_G2, 3: m.BLS12_381_G2}
 
 
@@ -93,6 +94,13 @@ def run_both(libs, cid, op, records, host_too=True):
         return out_h, out_h
     bad = np.nonzero((out_d != out_h).any(axis=1))[0]
     assert bad.size == 0, f"{op} curve {cid}: device and host limbs differ on {bad.size} of {n} records, first {bad[0]}: in={records[bad[0]].tolist()}"
+    if cid >= 2 and OPS["EL_MUL"] <= OPS[op] <= OPS["DBL"]:
+        # G2: the same records through the two-lanes-per-point form (csrc/fp2pair.hpp: lane h of a pair holds half h of every Fp2
+        # value, partner limbs by DPP) -- the product kernels behind option "g2_paired" -- must give the same LIMBS
+        out_p = np.full((n, ow.value), 0xEEEEEEEE, dtype=np.uint32)
+        assert dev.msm_devtest_run(cid, DT_PAIR + OPS[op], records.ctypes.data, out_p.ctypes.data, n) == 0
+        bad = np.nonzero((out_p != out_h).any(axis=1))[0]
+        assert bad.size == 0, f"{op} curve {cid}, paired lanes: limbs differ from the host on {bad.size} of {n} records, first {bad[0]}: in={records[bad[0]].tolist()}"
     return out_d, out_h
 
 

@@ -83,6 +83,32 @@ def test_accumulate_kernel_isa(law):
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
+@pytest.mark.parametrize("nb", [5, 1])
+def test_paired_g2_accumulate_kernel_isa(nb):
+    """G2 with every Fp2 value on two lanes (csrc/fp2pair.hpp, SwPairLaw): the point of the form is TWO waves per SIMD, so the
+    kernel must fit 256 registers with NO scratch (the one-lane form needs 356 and spilled 138-412 VGPRs at two waves:
+    profiles/r02_ab_g2_waves.txt), partner limbs must travel by DPP quad permutes (no LDS round trip, no ds_bpermute), and an Fp2
+    product must stay ONE fused dual product per lane: 10 per mixed addition (8M + 2S), 574 (p0 = 1) or 588 multiply-adds each."""
+    fq = "Bls12_377_Fq" if nb == 5 else "Bls12_381_Fq"
+    inst = ("template __global__ void k_accumulate_glds<SwPairLaw<%s, %d>>(const uint2*, const uint32_t*, uint32_t, "
+            "const AffineDevT<Fe2>*, SegOutT<Fe2>, uint32_t, uint32_t*);" % (fq, nb))
+    body, ops, res = _compile_kernel(inst)
+    assert res["scratch"] == 0 and res["occupancy"] >= 2 and res["vgprs"] <= 256, res
+    assert "s_set_gpr_idx_on" not in body and "v_accvgpr" not in body and "scratch_" not in body
+    assert "ds_bpermute" not in body and "ds_swizzle" not in body
+    per_mul = 574 if nb == 5 else 588
+    mads = ops.count("v_mad_u64_u32")
+    # the common path (10 products) plus the rare same-x branch (doubling of an affine point: 9 more), statically
+    assert 10 * per_mul <= mads <= 20 * per_mul, mads
+    dpp = body.count("quad_perm")
+    assert 6 * 42 <= dpp <= 20 * 42, dpp          # at most three permutes per limb and product; shared operands are permuted once
+    # a quad gathers the records of its TWO pairs: 2 records x 4 sectors by LDS-DMA, at the prologue and in the loop
+    assert ops.count("global_load_lds_dwordx4") == 2 * 2 * 4 and ops.count("ds_write_b128") == 0
+    assert 4 * (2 * 4 * 1024) <= res["lds"] <= 40 * 1024, res["lds"]     # 8 KB per wave (+ skew): two blocks per CU and room to spare
+    assert ops.count("v_cndmask_b32_e32") <= 20, ops.count("v_cndmask_b32_e32")
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
 def test_quad_addition_kernel_isa():
     """The latency form of the scan step: four lanes per addition (te.hpp te_add_quad).  Three multiplications per lane (the
     one-lane unified addition has nine), operands exchanged by DPP quad permutes, small enough for 4 waves/SIMD, no scratch."""

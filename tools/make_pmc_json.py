@@ -27,8 +27,9 @@ calib_path = sys.argv[4] if len(sys.argv) > 4 else os.path.join(ROOT, "profiles"
 CFG = {
     "377": dict(npow=26, c=20, windows=13, record=192, law="twisted Edwards (7M)", gather="calib_gather_glds<3>", entry="calib_gather_lane<1>", entries_per_refill=8),
     "381": dict(npow=26, c=20, windows=13, record=128, law="XYZZ (8M + 2S)", gather="calib_gather_glds<2>", entry="calib_gather_lane<1>", entries_per_refill=4),
-    "g2": dict(npow=24, c=20, windows=13, record=256, law="XYZZ over Fq2", gather="calib_gather_glds<4>", entry=None, entries_per_refill=1),
-    "381g2": dict(npow=24, c=20, windows=13, record=256, law="XYZZ over Fq2 (BLS12-381)", gather="calib_gather_glds<4>", entry=None, entries_per_refill=1),
+    # (round 5: two lanes per point, csrc/fp2pair.hpp -- the pair shares its entries, four per refill of the register queue)
+    "g2": dict(npow=24, c=20, windows=13, record=256, law="XYZZ over Fq2, two lanes per point", gather="calib_gather_glds<4>", entry=None, entries_per_refill=4),
+    "381g2": dict(npow=24, c=20, windows=13, record=256, law="XYZZ over Fq2 (BLS12-381), two lanes per point", gather="calib_gather_glds<4>", entry=None, entries_per_refill=4),
 }[curve]
 calib = {}
 if os.path.exists(calib_path):
@@ -105,7 +106,7 @@ res = {
     "plan": plan,
     "config": "bls12_%s npow=%d (c = %d, %d windows), the k_accumulate_glds launch of a bench step: %s, LDS-DMA quad-cooperative gathers of %d-B "
               "records, sorted (value, key) entries %s" % ({"377": "377_g1", "381": "381_g1", "g2": "377_g2", "381g2": "381_g2"}[curve], CFG["npow"], CFG["c"], CFG["windows"], CFG["law"],
-                                                           CFG["record"], "through a register queue (%d per refill)" % CFG["entries_per_refill"] if CFG["entry"] else "one per load"),
+                                                           CFG["record"], "through a register queue (%d per refill)" % CFG["entries_per_refill"] if CFG["entries_per_refill"] > 1 else "one per load"),
     "source": "tools/profile_gpu.sh: rocprofv3 --kernel-trace --pmc ..., one counter group per pass",
     "kernel_source_sha16": kernel_source_sha16(),
     "FETCH_SIZE_KiB": c.get("FETCH_SIZE"), "WRITE_SIZE_KiB": c.get("WRITE_SIZE"),
