@@ -124,8 +124,12 @@ def _debug_engine_link(jobs, objs, out, force: bool = False) -> str:
 def build_debug_engine(force: bool = False) -> str:
     """libmi355msm_debug.so (tests only): the host orchestration and the grouping unit compiled with -DMSM_DEBUG -- invariant checks
     after every grouping level and after the accumulation (csrc/partition.hpp; the reference keeps such a self-check, disabled, in
-    CMB Partition4096.cu:419-432) -- linked with the SAME kernel objects as the product.  tests/test_gpu_debug_build.py runs it."""
-    return _debug_engine_link(*_debug_engine_compile(force), force)
+    CMB Partition4096.cu:419-432) -- linked with the SAME kernel objects as the product, which are therefore brought up to date first
+    (a stand-alone call on a clean tree, or after a kernel header changed, would otherwise fail to link or check stale kernels).
+    tests/test_gpu_debug_build.py runs it."""
+    dbg = _debug_engine_compile(force)
+    build_engine(force)
+    return _debug_engine_link(*dbg, force)
 
 
 def build_hosttest(force: bool = False) -> str:

@@ -190,6 +190,21 @@ int choose_window_bits(size_t n, int scalar_bits, bool shared_buckets, bool fold
   return best;
 }
 
+// The shape of a table set for `n` bases: window size c and the number of table levels actually built for `want_levels` asked for (0 = a
+// level per window).  ONE place for build_tables, mi355_msm_plan and the automatic choice (the plan query derived its own).
+struct TableShape {
+  uint32_t c, levels, bsets;
+};
+TableShape table_shape(size_t n, int scalar_bits, long opt_window_bits, int want_levels) {
+  TableShape t{};
+  t.c = opt_window_bits ? (uint32_t)opt_window_bits : (uint32_t)choose_window_bits(n, scalar_bits, true, false, want_levels);
+  const uint32_t all_windows = (257 + t.c - 1) / t.c;
+  t.levels = want_levels > 0 ? std::min<uint32_t>((uint32_t)want_levels, all_windows) : all_windows;
+  t.bsets = ceil_div(all_windows, t.levels);
+  t.levels = ceil_div(all_windows, t.bsets);
+  return t;
+}
+
 struct Plan {
   uint32_t c, windows, half, keybits;
   uint32_t bucket_windows;  // windows that own buckets: `windows`; with precomputed tables the bucket sets G = ceil(windows / levels)
@@ -249,6 +264,10 @@ struct mi355_msm_ctx {
   uint32_t te_fallback_streak = 0;   // consecutive chunks that fell back; two in a row demote the context to XYZZ for good
   uint64_t te_demotions = 0;
   uint64_t oom_backoffs = 0;      // chunks restarted with half the chunk size after a device allocation failed
+  uint64_t peer_stagings = 0;     // sharded contexts: slices (bases or scalars) pulled from ANOTHER device's memory into a shard's own (msm_sharded.hpp)
+  long opt_force_peer_staging = 0;   // test hook: take those branches although the source lies on the shard's own device (logical shards)
+  uint32_t last_bucket_windows = 0, last_l1_bits = 0, last_l1_bins = 0, last_passes = 0;   // grouping geometry of the most recent chunk
+  uint32_t auto_levels = 0;       // "precompute" = 2: the table levels chosen from the free HBM at the last set_bases (0 = none)
   uint64_t debug_checks = 0;      // -DMSM_DEBUG builds: invariant checks run so far (csrc/partition.hpp)
   size_t chunk_cap = 0;           // what the most recent run had to cap its chunks at after an allocation failed (0 = it never had to); reported, not kept
   size_t fitted_chunk = 0;        // largest chunk that has run with the current buffers and options (skips the fit query)
@@ -513,17 +532,17 @@ void convert_bases(mi355_msm_ctx* ctx, const uint8_t* d_raw, size_t n, size_t st
 // is the number of bucket sets (k = windows, G = 1: a level per window, the round-1..3 form; CMB PrecomputePoints.cu:10-39 builds
 // k = 6 levels 2^(46 j) P for its 23-bit windows, i.e. G = 2).
 template <class C>
-void build_tables(mi355_msm_ctx* ctx, const uint8_t* d_raw, size_t n, size_t stride, hipStream_t st) {
+void build_tables(mi355_msm_ctx* ctx, const uint8_t* d_raw, size_t n, size_t stride, int want_levels, hipStream_t st) {
   using E = typename C::E;
   using El = typename E::T;
   using AD = AffineDevT<El>;
   using XD = XyzzDevT<El>;
-  const int want_levels = (int)ctx->opt_table_levels;
-  const uint32_t c = ctx->opt_window_bits ? (uint32_t)ctx->opt_window_bits : (uint32_t)choose_window_bits(n, C::SCALAR_BITS, true, false, want_levels);
-  const uint32_t all_windows = (257 + c - 1) / c;
-  uint32_t windows = want_levels > 0 ? std::min<uint32_t>((uint32_t)want_levels, all_windows) : all_windows;   // = table levels from here on
-  const uint32_t bsets = ceil_div(all_windows, windows);
-  windows = ceil_div(all_windows, bsets);
+  if (ctx->opt_precompute == 2 && ctx->inject_alloc_failures > 0) {   // (test hook: the automatic choice must survive a failed build)
+    ctx->inject_alloc_failures--;
+    throw HipFailure((int)hipErrorOutOfMemory, "table allocation failed: out of memory (injected by the inject_alloc_failures test hook)");
+  }
+  const TableShape ts = table_shape(n, C::SCALAR_BITS, ctx->opt_window_bits, want_levels);
+  const uint32_t c = ts.c, windows = ts.levels /* = table levels from here on */, bsets = ts.bsets;
   const uint32_t level_shift = c * bsets;   // doublings between two levels
   if ((uint64_t)windows * n >= (1ull << 31)) bad_arg("precompute: %u tables of %zu points exceed the 2^31 index range", windows, n);
   const size_t table_bytes = (size_t)windows * n * sizeof(AD);
@@ -602,6 +621,120 @@ void build_te(mi355_msm_ctx* ctx, size_t n, hipStream_t st) {
   }
 }
 
+// "precompute" = 2: the table levels this base set gets, from the device memory that is free NOW (what the context already holds for
+// bases counts as free: it is replaced).  Candidates are the shapes profiles/r04_table_levels_sweep.txt shows as wins at 2^26 pairs -- a
+// level per window (-6 %, 151 GB with the Edwards records), 6 levels (-3 %, 86 GB), 4 (-1.4 %, 60 GB), 3 (-1 %, 47 GB); two levels lose --
+// tried largest first; each must fit with its build temporaries AND leave the work buffers of a full chunk plus a tenth of the device to
+// the caller.  -1 = no tables (small inputs, where tables were never measured to pay, or not enough memory: none under ~64 GB free at 2^26).
+int precompute_auto_levels(mi355_msm_ctx* ctx, size_t n) {
+  if (n < ((size_t)1 << 24)) return -1;
+  size_t free_b = 0, total_b = 0;
+  HIP_OK(hipMemGetInfo(&free_b, &total_b));
+  size_t held = ctx->bases.bytes + ctx->te_bases.bytes + ctx->inf.bytes, nb = 0;
+  DevBuf* const* wb = work_buffers(ctx, nb);
+  for (size_t i = 0; i < nb; i++) held += wb[i]->bytes;
+  uint64_t avail = (uint64_t)free_b + held;
+  const uint64_t reserve = total_b / 10;
+  avail = avail > reserve ? avail - reserve : 0;
+  if (ctx->opt_mem_limit > 0 && (uint64_t)ctx->opt_mem_limit < avail) avail = (uint64_t)ctx->opt_mem_limit;   // (test hook)
+  const uint64_t el = is_g2(ctx->curve) ? 2 : 1;
+  const bool te = ctx->curve == MI355_BLS12_377_G1 && ctx->opt_twisted_edwards;
+  for (int want : {0, 6, 4, 3}) {
+    const TableShape ts = table_shape(n, ctx->scalar_bits(), ctx->opt_window_bits, want);
+    if (want > 0 && ts.levels > (uint32_t)want) continue;
+    if ((uint64_t)ts.levels * n >= (1ull << 31) || ts.levels < 2) continue;
+    const uint64_t sw = (uint64_t)ts.levels * n * 128 * el, inf = (uint64_t)ts.levels * n;
+    const uint64_t te_b = te ? (uint64_t)ts.levels * n * sizeof(TeAffineDev) : 0;
+    // peak of the build: the streamed Edwards build holds three short-Weierstrass levels, every Edwards level and one XYZZ + prefix array
+    // (build_tables_te_streamed); the plain build every level and the same temporaries
+    const uint64_t build = te ? 3 * n * 128 + te_b + n * (224 + 56) : sw + n * (224 + 56) * el;
+    mi355_msm_ctx tmp;   // (planning arithmetic only)
+    tmp.curve = ctx->curve;
+    tmp.pre_c = ts.c;
+    tmp.pre_windows = ts.levels;
+    const Plan p = tmp.plan(std::min(n, (size_t)1 << 26));
+    const uint64_t steady = (te ? n * 128 * el + te_b : sw) + inf + work_bytes(p, el) + n * 32;
+    const uint64_t need = std::max(build + inf, steady);
+    if (need + (need >> 4) <= avail) return want;
+  }
+  return -1;
+}
+
+// Tables AND their twisted-Edwards records in one sweep (BLS12-377 G1 with the Edwards path on -- the default): level w of the
+// short-Weierstrass table exists only to produce level w + 1 and its own Edwards record, so two rotating level buffers (+ level 0, which
+// the rare XYZZ fallback keeps) replace the whole table.  build_tables + build_te hold every level of BOTH forms at once -- 95 + 142 GB
+// for a level per window at 2^26 -- which is why "precompute" = auto could not afford the best shape on an idle 288-GB device; this
+// way the peak is 3 x 8.6 + 142 + 19 GB.  Returns false -- nothing kept -- when a point of some level has no Edwards image (a base set
+// off the odd-order subgroup): the caller then builds the plain tables.
+bool build_tables_te_streamed(mi355_msm_ctx* ctx, const uint8_t* d_raw, size_t n, size_t stride, int want_levels, hipStream_t st) {
+  using C = Bls12_377_G1;
+  using E = C::E;
+  if (ctx->opt_precompute == 2 && ctx->inject_alloc_failures > 0) {   // (test hook: the automatic choice must survive a failed build)
+    ctx->inject_alloc_failures--;
+    throw HipFailure((int)hipErrorOutOfMemory, "table allocation failed: out of memory (injected by the inject_alloc_failures test hook)");
+  }
+  const TableShape ts = table_shape(n, C::SCALAR_BITS, ctx->opt_window_bits, want_levels);
+  const uint32_t levels = ts.levels, level_shift = ts.c * ts.bsets;
+  if ((uint64_t)levels * n >= (1ull << 31)) bad_arg("precompute: %u tables of %zu points exceed the 2^31 index range", levels, n);
+  if (levels < 2) return false;
+  const size_t need = (size_t)levels * n * sizeof(TeAffineDev) + 3 * n * sizeof(AffineDev) + n * (sizeof(XyzzDev) + sizeof(Fe)) + (size_t)levels * n;
+  size_t free_b = 0, total_b = 0;
+  HIP_OK(hipMemGetInfo(&free_b, &total_b));
+  if (need > free_b + ctx->bases.bytes + ctx->te_bases.bytes + ctx->inf.bytes)
+    bad_arg("precompute: %u table levels of %zu points need %zu MiB, only %zu MiB free", levels, n, need >> 20, free_b >> 20);
+  DevBuf xyzz, prefix;
+  bool ok = false;
+  try {
+    ctx->te_bases.reserve((size_t)levels * n * sizeof(TeAffineDev));
+    ctx->bases.reserve(3 * n * sizeof(AffineDev));       // slot 0 = level 0 (kept), slots 1 / 2 = the two most recent levels
+    ctx->inf.reserve((size_t)levels * n);
+    ctx->flags.reserve(2 * sizeof(uint32_t));
+    if (!ctx->h_flags) HIP_OK(hipHostMalloc((void**)&ctx->h_flags, 2 * sizeof(uint32_t), hipHostMallocDefault));
+    HIP_OK(hipMemsetAsync(ctx->flags.p, 0, 2 * sizeof(uint32_t), st));
+    xyzz.reserve(n * sizeof(XyzzDev));
+    prefix.reserve(n * sizeof(Fe));
+    AffineDev* const slots = ctx->bases.as<AffineDev>();
+    uint8_t* const inf = ctx->inf.as<uint8_t>();
+    auto slot_of = [&](uint32_t w) { return slots + (size_t)(w == 0 ? 0 : 1 + ((w - 1) & 1)) * n; };
+    HIP_OK(Launch<E>::convert_bases(d_raw, stride, (uint32_t)n, ctx->bases_serialized, slot_of(0), inf, st));
+    for (uint32_t w = 0; w < levels; w++) {
+      if (w > 0) {
+        HIP_OK(Launch<E>::pre_double(slot_of(w - 1), inf + (size_t)(w - 1) * n, (uint32_t)n, level_shift, xyzz.as<XyzzDev>(), st));
+        HIP_OK(Launch<E>::pre_normalize(xyzz.as<XyzzDev>(), (uint32_t)n, 64, prefix.as<Fe>(), slot_of(w), inf + (size_t)w * n, st));
+      }
+      HIP_OK(LaunchTe::convert(slot_of(w), inf + (size_t)w * n, (uint32_t)n, 64, prefix.as<Fe>(), ctx->te_bases.as<TeAffineDev>() + (size_t)w * n,
+                               ctx->flags.as<uint32_t>(), st));
+    }
+    HIP_OK(hipMemcpyAsync(ctx->h_flags, ctx->flags.p, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
+    ok = ctx->h_flags[0] == 0;
+    if (ok) {
+      // keep level 0 of the short-Weierstrass form only: it serves the (rare) XYZZ fallback, without tables
+      DevBuf level0;
+      level0.reserve(n * sizeof(AffineDev));
+      HIP_OK(hipMemcpy(level0.p, ctx->bases.p, n * sizeof(AffineDev), hipMemcpyDeviceToDevice));
+      ctx->bases.release();
+      ctx->bases = level0;
+    }
+  } catch (...) {
+    xyzz.release();
+    prefix.release();
+    ctx->te_bases.release();
+    throw;
+  }
+  xyzz.release();
+  prefix.release();
+  if (!ok) {
+    ctx->te_bases.release();
+    return false;
+  }
+  ctx->pre_c = ts.c;
+  ctx->pre_windows = levels;
+  ctx->te_active = true;
+  ctx->sw_level0_only = true;
+  return true;
+}
+
 void set_bases_device(mi355_msm_ctx* ctx, const void* d_affine, size_t n, size_t stride) {
   ensure_device(ctx);
   const size_t min_stride = 2 * coord_bytes(ctx->curve) + (ctx->bases_serialized ? 0 : 1);
@@ -613,13 +746,37 @@ void set_bases_device(mi355_msm_ctx* ctx, const void* d_affine, size_t n, size_t
   ctx->te_active = false;
   ctx->te_fallback_streak = 0;
   ctx->sw_level0_only = false;
+  ctx->auto_levels = 0;
+  bool te_done = false;   // the Edwards records were built together with the tables (build_tables_te_streamed)
   if (n) {
-    if (ctx->opt_precompute)
-      with_curve(ctx->curve, [&]<class C>() { build_tables<C>(ctx, (const uint8_t*)d_affine, n, stride, ctx->own_stream); });
-    else
+    bool tables = ctx->opt_precompute == 1;
+    int want_levels = (int)ctx->opt_table_levels;
+    if (ctx->opt_precompute == 2) {
+      want_levels = precompute_auto_levels(ctx, n);
+      tables = want_levels >= 0;
+    }
+    if (tables) {
+      try {
+        if (ctx->curve == MI355_BLS12_377_G1 && ctx->opt_twisted_edwards)
+          te_done = build_tables_te_streamed(ctx, (const uint8_t*)d_affine, n, stride, want_levels, ctx->own_stream);
+        if (!te_done)
+          with_curve(ctx->curve, [&]<class C>() { build_tables<C>(ctx, (const uint8_t*)d_affine, n, stride, want_levels, ctx->own_stream); });
+      } catch (const HipFailure& e) {
+        // auto: tables are an optimisation -- a build that runs out of memory after all (another tenant took it meanwhile) leaves the
+        // context on the table-free path instead of failing set_bases
+        if (ctx->opt_precompute != 2 || (e.code != (int)hipErrorOutOfMemory && e.code != -1)) throw;
+        (void)hipGetLastError();
+        ctx->pre_c = ctx->pre_windows = 0;
+        ctx->bases.release();
+        ctx->inf.release();
+        tables = false;
+      }
+    }
+    if (!tables)
       with_curve(ctx->curve, [&]<class C>() { convert_bases<C>(ctx, (const uint8_t*)d_affine, n, stride, ctx->own_stream); });
+    if (ctx->opt_precompute == 2 && tables) ctx->auto_levels = ctx->pre_windows;
     HIP_OK(hipStreamSynchronize(ctx->own_stream));
-    if (ctx->curve == MI355_BLS12_377_G1 && ctx->opt_twisted_edwards) build_te(ctx, n, ctx->own_stream);
+    if (ctx->curve == MI355_BLS12_377_G1 && ctx->opt_twisted_edwards && !te_done) build_te(ctx, n, ctx->own_stream);
   }
   ctx->nbases = n;
 }
@@ -815,6 +972,13 @@ bool run_chunk_impl(mi355_msm_ctx* ctx, const uint32_t* d_scalars, size_t base0,
   ctx->last_info[4] += 1;
   ctx->last_info[5] = p.nlanes;
   ctx->last_info[7] = TE ? 1 : 0;
+  ctx->last_bucket_windows = p.bucket_windows;
+  ctx->last_l1_bits = gp.hb;
+  ctx->last_l1_bins = gp.nbins;
+  {
+    uint32_t rb_[4];
+    ctx->last_passes = (uint32_t)part_pass_bits(gp.lb, rb_);
+  }
   if (carry && !carry->last) {
     // nothing to reduce yet, nothing to wait for: the next chunk's kernels queue up behind these
     HIP_OK(hipEventRecord(ev[5], st));
@@ -1036,6 +1200,7 @@ void run_device_t(mi355_msm_ctx* ctx, uint8_t* out, const uint32_t* d_scalars, s
     // A batch that runs as several chunks carries one bucket array through them (BucketCarry): decided at its first chunk
     BucketCarry carry{};
     bool carried = false, allow_te = true;
+    size_t reclaimed_at = (size_t)-1;   // chunk position at which the idle stateless contexts were last reclaimed
     for (size_t off = 0; off < n;) {
       // plan the chunk against the memory that is there (ML msm.cu:453-466 plans first, too) ...
       const bool tables_now = ctx->pre_c && ((ctx->te_active && allow_te) || !ctx->sw_level0_only);
@@ -1101,7 +1266,11 @@ void run_device_t(mi355_msm_ctx* ctx, uint8_t* out, const uint32_t* d_scalars, s
         (void)hipStreamSynchronize(st);
         release_work_buffers(ctx, carried && off > 0);
         // memory this library still holds behind the caller's back (parked stateless contexts) goes first: same chunk again
-        if (reclaim_idle_device_memory()) continue;
+        // (once per chunk position: concurrent callers that keep parking contexts must not keep this loop spinning -- ADVICE r4)
+        if (reclaimed_at != off && reclaim_idle_device_memory()) {
+          reclaimed_at = off;
+          continue;
+        }
         max_chunk = ctx->chunk_cap = (cn + 1) / 2;   // for the rest of this run
         ctx->oom_backoffs++;
         continue;
@@ -1287,13 +1456,17 @@ RustError mi355_msm_create_env(mi355_msm_ctx** out, int curve) {
   if (e.code || !out || !*out) return e;
   // MI355_MSM_ASSUME_SUBGROUP = 0 | 1: the harness's bases are (are not) all in the order-r subgroup -- option "assume_subgroup"
   const char* sub = getenv("MI355_MSM_ASSUME_SUBGROUP");
-  if (sub && *sub) {
-    e = mi355_msm_set_option(*out, "assume_subgroup", atol(sub) != 0);
-    if (e.code) {
-      RustError d = mi355_msm_destroy(*out);
-      if (d.message) free(d.message);
-      *out = nullptr;
-    }
+  if (sub && *sub) e = mi355_msm_set_option(*out, "assume_subgroup", atol(sub) != 0);
+  // MI355_MSM_PRECOMPUTE = auto | 0 | 1 (+ MI355_MSM_TABLE_LEVELS = k): the harness's init is untimed (CMB MSM.cu:380-383 builds its
+  // tables there), so a harness that owns the GPU may let the context spend free HBM on tables -- options "precompute" / "table_levels"
+  const char* pre = getenv("MI355_MSM_PRECOMPUTE");
+  if (!e.code && pre && *pre) e = mi355_msm_set_option(*out, "precompute", strcmp(pre, "auto") == 0 ? 2 : (atol(pre) != 0 ? 1 : 0));
+  const char* lv = getenv("MI355_MSM_TABLE_LEVELS");
+  if (!e.code && lv && *lv) e = mi355_msm_set_option(*out, "table_levels", atol(lv));
+  if (e.code) {
+    RustError d = mi355_msm_destroy(*out);
+    if (d.message) free(d.message);
+    *out = nullptr;
   }
   return e;
 }
@@ -1386,6 +1559,10 @@ RustError mi355_msm_set_option(mi355_msm_ctx* ctx, const char* key, long value) 
   return guarded([&] {
     if (!ctx || !key) bad_arg("null argument");
     std::string k(key);
+    if (k == "force_peer_staging") {   // test hook of a sharded context (msm_sharded.hpp); lives in the parent
+      ctx->opt_force_peer_staging = value != 0;
+      return;
+    }
     if (!ctx->shards.empty() && k != "combine") {
       for (mi355_msm_ctx* sh : ctx->shards) {
         RustError e = mi355_msm_set_option(sh, key, value);
@@ -1439,7 +1616,10 @@ RustError mi355_msm_set_option(mi355_msm_ctx* ctx, const char* key, long value) 
     } else if (k == "twisted_edwards") {
       ctx->opt_twisted_edwards = value != 0;   // takes effect at the next set_bases
     } else if (k == "precompute") {
-      ctx->opt_precompute = value != 0;   // takes effect at the next set_bases
+      // 0 none; 1 tables ("table_levels" of them); 2 = auto: as many levels as the HBM that is free at set_bases pays for, none when
+      // that is short (precompute_auto_levels).  Takes effect at the next set_bases.
+      if (value < 0 || value > 2) bad_arg("precompute %ld out of range [0, 2]", value);
+      ctx->opt_precompute = value;
     } else if (k == "table_levels") {
       // with "precompute": how many table levels to build (0 = one per window, every window then shares ONE bucket set).  With k levels
       // the windows g, g + G, g + 2G, ... share bucket set g (G = ceil(windows / k)): k times the base memory instead of `windows` times
@@ -1515,6 +1695,10 @@ RustError mi355_msm_query(mi355_msm_ctx* ctx, const char* key, uint64_t* value) 
       *value = ctx->rccl_exchanges;
       return;
     }
+    if (k == "peer_stagings") {
+      *value = ctx->peer_stagings;
+      return;
+    }
     if (!ctx->shards.empty()) {
       // counters add up over the shards; "twisted_edwards" is 1 only if every shard runs on that path
       uint64_t sum = 0, all = 1;
@@ -1559,6 +1743,18 @@ RustError mi355_msm_query(mi355_msm_ctx* ctx, const char* key, uint64_t* value) 
       *value = ctx->pre_c;
     else if (k == "base_bytes")
       *value = ctx->bases.bytes + ctx->te_bases.bytes + ctx->inf.bytes;
+    else if (k == "bucket_windows")   // of the most recent chunk: bucket sets the reduction walks (= windows without tables)
+      *value = ctx->last_bucket_windows;
+    else if (k == "l1_bits")          // ... bucket bits level 1 of the grouping resolved, its bins, and the generic passes behind it
+      *value = ctx->last_l1_bits;
+    else if (k == "l1_bins")
+      *value = ctx->last_l1_bins;
+    else if (k == "group_passes")
+      *value = ctx->last_passes;
+    else if (k == "precompute")       // 0 none, 1 tables as asked for, 2 = auto (see "table_levels" for what it chose)
+      *value = (uint64_t)ctx->opt_precompute;
+    else if (k == "g2_paired")
+      *value = (uint64_t)ctx->opt_g2_paired;
     else
       bad_arg("unknown query '%s'", key);
   });
@@ -1691,9 +1887,12 @@ RustError mi355_msm_plan(int curve, size_t npoints, int precompute, const long* 
     }
     if (tmp.opt_window_bits && (tmp.opt_window_bits < 2 || tmp.opt_window_bits > 24)) bad_arg("window_bits out of range");
     if (tmp.opt_seg_entries && tmp.opt_seg_entries < 4) bad_arg("seg_entries out of range");
+    if (precompute < 0) bad_arg("precompute must be >= 0");
     if (precompute) {
-      tmp.pre_c = tmp.opt_window_bits ? (uint32_t)tmp.opt_window_bits : (uint32_t)choose_window_bits(npoints, tmp.scalar_bits(), true);
-      tmp.pre_windows = (257 + tmp.pre_c - 1) / tmp.pre_c;   // a table level per window
+      // 1 = a table level per window, k > 1 = the context option "table_levels" = k: the very shape build_tables gives the context
+      const TableShape ts = table_shape(npoints, tmp.scalar_bits(), tmp.opt_window_bits, precompute > 1 ? precompute : 0);
+      tmp.pre_c = ts.c;
+      tmp.pre_windows = ts.levels;
     }
     const Plan p = tmp.plan(npoints);
     // fragment-merge levels: n slots -> 2*ceil(n/segK) until one lane is left

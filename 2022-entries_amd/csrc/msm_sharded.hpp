@@ -217,10 +217,13 @@ static void sharded_set_bases(mi355_msm_ctx* ctx, const void* data, size_t n, si
       return;
     }
     ensure_device(sh);
-    if (src_dev == sh->device || cnt == 0) {
+    // ("force_peer_staging": test hook -- logical shards share one device, so the branch below would otherwise first execute on the
+    //  first multi-GPU box; the copy is then device-local, everything else is the code a peer pull runs)
+    if ((src_dev == sh->device && !ctx->opt_force_peer_staging) || cnt == 0) {
       set_bases_device(sh, src, cnt, stride);
       return;
     }
+    __atomic_fetch_add(&ctx->peer_stagings, 1, __ATOMIC_RELAXED);
     DevBuf stage;
     try {
       stage.reserve(cnt * stride);
@@ -339,10 +342,11 @@ static void sharded_run(mi355_msm_ctx* ctx, void* out, const void* scalars, size
       return;
     }
     ensure_device(sh);
-    if (src_dev == sh->device || cnt == 0) {
+    if ((src_dev == sh->device && !ctx->opt_force_peer_staging) || cnt == 0) {
       run_device(sh, po, src, cnt, batches, n, sh->own_stream);
       return;
     }
+    __atomic_fetch_add(&ctx->peer_stagings, 1, __ATOMIC_RELAXED);
     // another GPU's memory: pull this shard's slice of every batch over xGMI, then run on the local copy
     sh->scalars.reserve(std::max<size_t>(cnt * batches * 32, 32));
     for (size_t b = 0; b < batches; b++)

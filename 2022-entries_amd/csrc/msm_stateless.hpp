@@ -124,12 +124,30 @@ struct StatelessLease {
         ctx->inf.release();
         for (DevBuf& r : ctx->stateless_raw) r.release();
       }
-      std::lock_guard<std::mutex> lk(g_ring_mu);
-      bool taken = false;
-      for (mi355_msm_ctx* c : g_stateless_idle) taken = taken || (c->curve == ctx->curve && c->device == ctx->device);
-      if (!taken) {
-        g_stateless_idle.push_back(ctx);
-        ctx = nullptr;
+      std::vector<mi355_msm_ctx*> evict;
+      {
+        std::lock_guard<std::mutex> lk(g_ring_mu);
+        bool taken = false;
+        for (mi355_msm_ctx* c : g_stateless_idle) taken = taken || (c->curve == ctx->curve && c->device == ctx->device);
+        if (!taken) {
+          // the bound is on what sits idle on the DEVICE, all curves together (four curves x 16 GB could sit there while
+          // another allocator of the process -- torch, RCCL -- runs out): the contexts parked longest go first
+          size_t idle = ctx_device_bytes(ctx);
+          for (mi355_msm_ctx* c : g_stateless_idle)
+            if (c->device == ctx->device) idle += ctx_device_bytes(c);
+          for (size_t i = 0; i < g_stateless_idle.size() && idle > ((size_t)keep_mb << 20);) {
+            if (g_stateless_idle[i]->device != ctx->device) { i++; continue; }
+            idle -= ctx_device_bytes(g_stateless_idle[i]);
+            evict.push_back(g_stateless_idle[i]);
+            g_stateless_idle.erase(g_stateless_idle.begin() + (long)i);
+          }
+          g_stateless_idle.push_back(ctx);
+          ctx = nullptr;
+        }
+      }
+      for (mi355_msm_ctx* c : evict) {
+        RustError d = mi355_msm_destroy(c);
+        if (d.message) free(d.message);
       }
     }
     if (ctx) {   // a failed call, or the slot of this (curve, device) is taken: one idle context per key, no more
@@ -328,6 +346,7 @@ void stateless_t(mi355_msm_ctx* ctx, uint8_t* out, const uint8_t* affine, size_t
         ctx->nbases = cnt;
         // the slice as chunks of the ordinary pipeline (one, unless device memory is short)
         size_t max_chunk = ctx->opt_max_chunk ? (size_t)ctx->opt_max_chunk : ((size_t)1 << 26);
+        size_t reclaimed_at = (size_t)-1;
         for (size_t off = 0; off < cnt;) {
           size_t cn = std::min(max_chunk, cnt - off);
           if (cn > ctx->fitted_chunk) cn = fit_chunk(ctx, cn, false, carry_c);
@@ -339,7 +358,10 @@ void stateless_t(mi355_msm_ctx* ctx, uint8_t* out, const uint8_t* affine, size_t
             if (e.code != (int)hipErrorOutOfMemory || cn <= 1024) throw;
             (void)hipStreamSynchronize(st);
             release_work_buffers(ctx, carry_c && !carry.first);   // (the totals of the slices so far stay)
-            if (reclaim_idle_device_memory()) continue;           // parked contexts of other curves / devices go first
+            if (reclaimed_at != off && reclaim_idle_device_memory()) {   // parked contexts of other curves / devices go first, once
+              reclaimed_at = off;
+              continue;
+            }
             max_chunk = ctx->chunk_cap = (cn + 1) / 2;
             ctx->oom_backoffs++;
             continue;

@@ -93,7 +93,7 @@ void stream_flush(mi355_msm_stream* s) {
     struct Restore {
       mi355_msm_ctx* c;
       ~Restore() {
-        for (const char* k : {"scalars_montgomery", "window_bits"}) {
+        for (const char* k : {"scalars_montgomery", "window_bits", "assume_subgroup"}) {
           RustError e = mi355_msm_set_option(c, k, 0);
           if (e.message) free(e.message);
         }
@@ -101,6 +101,12 @@ void stream_flush(mi355_msm_stream* s) {
     } restore{ws.ctx};
     take(mi355_msm_set_option(ws.ctx, "scalars_montgomery", s->opt_scalars_montgomery));
     take(mi355_msm_set_option(ws.ctx, "window_bits", s->opt_window_bits));
+    // (a pooled context keeps whatever the last stateless call set: the accumulators are exact for any curve point unless the
+    //  environment says the bases are in the subgroup, as for mi355_msm -- ADVICE r4)
+    {
+      const char* sub_env = getenv("MI355_MSM_ASSUME_SUBGROUP");
+      take(mi355_msm_set_option(ws.ctx, "assume_subgroup", (sub_env && *sub_env && atol(sub_env) != 0) ? 1 : 0));
+    }
     stateless_run(ws.ctx, two.data() + pb, s->bases.data(), n, s->scalars.data(), s->stride);
     ws.keep();
   }

@@ -267,7 +267,8 @@ class MultiScalarMultContext:
 
     def query(self, key: str) -> int:
         """Context state: "twisted_edwards", "twisted_edwards_fallbacks", "twisted_edwards_demotions", "oom_backoffs", "chunk_cap",
-        "device", "shards", "rccl_exchanges", "bases", "table_levels", "table_window_bits", "base_bytes", "assume_subgroup", "carry"."""
+        "device", "shards", "rccl_exchanges", "peer_stagings", "bases", "table_levels", "table_window_bits", "base_bytes", "assume_subgroup",
+        "carry", "precompute", "g2_paired", and the geometry of the most recent chunk: "bucket_windows", "l1_bits", "l1_bins", "group_passes"."""
         v = ctypes.c_uint64(0)
         _check(self._lib.mi355_msm_query(self.context, key.encode(), ctypes.byref(v)))
         return int(v.value)
@@ -497,12 +498,16 @@ def generate_points(npoints: int, distinct: int = 1 << 15, seed: int = 0x5A50524
 
 
 def plan(npoints: int, curve="bls12_377_g1", precompute: bool = False, window_bits: int = 0, lane_entries: int = 0,
-         seg_entries: int = 0) -> dict:
-    """The engine's execution plan for an MSM of ``npoints`` pairs (host arithmetic only; works without a GPU)."""
+         seg_entries: int = 0, table_levels: int = 0) -> dict:
+    """The engine's execution plan for an MSM of ``npoints`` pairs (host arithmetic only; works without a GPU).
+    ``precompute`` with ``table_levels`` = k > 1 plans what a context with those two options runs (k levels, ceil(windows / k)
+    bucket sets); ``table_levels`` = 0 is a level per window."""
     lib = load_library()
     opts = (ctypes.c_long * 3)(window_bits, lane_entries, seg_entries)
     out = (ctypes.c_uint64 * 10)()
-    _check(lib.mi355_msm_plan(_curve_id(curve), npoints, 1 if precompute else 0, opts, out))
+    if table_levels == 1:
+        raise ValueError("table_levels = 1 is no table at all: pass precompute=False")
+    _check(lib.mi355_msm_plan(_curve_id(curve), npoints, (table_levels if table_levels > 1 else 1) if precompute else 0, opts, out))
     names = ("window_bits", "windows", "bucket_windows", "entries", "lane_entries", "lanes", "merge_launches", "reduce_launches",
              "key_bits", "work_bytes")
     return {k: int(out[i]) for i, k in enumerate(names)}

@@ -117,7 +117,14 @@ RustError mi355_msm_run(mi355_msm_ctx* ctx, void* out_projective, const void* sc
 RustError mi355_msm_run_device(mi355_msm_ctx* ctx, void* out_projective, const void* d_scalars, size_t npoints,
                                size_t batches, void* stream);
 
-/* "precompute" = 1 (set BEFORE set_bases) makes the context store the tables 2^(c w) * P_i for every window w, so all digits
+/* "precompute" = 2 (auto, set BEFORE set_bases): the context picks the table levels itself from the device memory that is free at
+ * set_bases -- a level per window, else 6, 4 or 3 levels (the shapes profiles/r04_table_levels_sweep.txt shows as wins: -6 % / -3 % /
+ * -1.4 % / -1 % at 2^26 pairs), each only if it fits with its build temporaries and leaves the work buffers of a full chunk plus a
+ * tenth of the device to the caller; none below 2^24 pairs or when memory is short (about 64 GB free at 2^26), and a build that
+ * fails all the same leaves the context on the table-free path.  mi355_msm_query "table_levels" says what it chose.  The harness
+ * shims take it from the environment: MI355_MSM_PRECOMPUTE=auto|0|1 (the reference's init builds its tables untimed,
+ * CMB MSM.cu:380-383).
+ * "precompute" = 1 (set BEFORE set_bases) makes the context store the tables 2^(c w) * P_i for every window w, so all digits
  * of a scalar share one bucket set and the bucket->window reduction and the window fold shrink by the number of windows --
  * the fixed-base trick of the ZPrize winners (CMB PrecomputePoints.cu:10-39; P1A matter-labs/src/lib.rs:101-114), paid for in
  * the untimed init and in HBM (windows x 128 B per base: 94 GB at 2^26, 151 GB with the Edwards records).  Results are identical.
@@ -238,7 +245,9 @@ RustError mi355_msm_generate_points(int curve, uint64_t seed, size_t distinct, s
 /* The execution plan the engine would use for an MSM of `npoints` pairs (pure host arithmetic, no device): out[0..9] =
  * window bits, digit windows, windows owning buckets (1 with precompute), sorted entries, entries per lane, lanes,
  * fragment-merge launches, bucket-reduce launches, sort key bits, bytes of per-run device work buffers.
- * `options` may be NULL or {window_bits, lane_entries, seg_entries} (0 = automatic). */
+ * `options` may be NULL or {window_bits, lane_entries, seg_entries} (0 = automatic).  `precompute`: 0 = no tables, 1 = a table
+ * level per window, k > 1 = the context option "table_levels" = k -- the plan then equals what a context with those options
+ * reports through mi355_msm_query "table_window_bits" / "table_levels". */
 RustError mi355_msm_plan(int curve, size_t npoints, int precompute, const long* options, uint64_t* out);
 
 /* The slice [*lo, *hi) of range(npoints) that shard `shard` of `nshards` owns in a sharded context (and in dist.py's

@@ -323,6 +323,75 @@ def test_table_levels(ea, oracle, golden, torch_cuda, curve_name, cid, rid):
         ctx.close()
 
 
+def test_plan_matches_context_for_table_levels(ea, torch_cuda):
+    """mi355_msm_plan with table levels plans what build_tables builds (one shared helper since round 5): window bits and
+    levels of the plan equal the context's "table_window_bits" / "table_levels", and its bucket sets equal what the run reports."""
+    n = 1 << 14
+    bases = ea.generate_points(n, distinct=200, seed=4)
+    sc = rand_scalars_np(0, n, 5)
+    for k in (0, 2, 3, 6):
+        ctx = ea.MultiScalarMultContext("bls12_377_g1")
+        ctx.set_option("precompute", 1)
+        ctx.set_option("table_levels", k)
+        ctx.set_bases(bases)
+        pl = ea.plan(n, "bls12_377_g1", precompute=True, table_levels=k)
+        assert pl["window_bits"] == ctx.query("table_window_bits"), k
+        levels = ctx.query("table_levels")
+        assert pl["bucket_windows"] == -(-pl["windows"] // levels), (k, pl, levels)
+        ctx.run(sc)
+        assert ctx.query("bucket_windows") == pl["bucket_windows"] and ctx.last_timings()["window_bits"] == pl["window_bits"]
+        ctx.close()
+
+
+@pytest.mark.parametrize("curve_name,cid,rid", [("bls12_377_g1", 0, 0), ("bls12_381_g1", 1, 1)])
+def test_precompute_auto(ea, oracle, torch_cuda, curve_name, cid, rid):
+    """ "precompute" = 2: the context chooses its table levels from the free device memory at set_bases (csrc/msm_engine.hip
+    precompute_auto_levels; the reference builds its tables in the untimed init, CMB MSM.cu:380-383).  Small inputs get none; at
+    2^24 pairs the choice follows the memory it is given (test hook "mem_limit"): everything -> a level per window, less -> 6 / 4 / 3
+    levels, too little -> none; a table build that fails all the same (injected) leaves the context on the table-free path.  Every
+    choice returns the bytes of the table-free run, which an oracle-checked prefix pins."""
+    torch = torch_cuda
+    small = ea.generate_points(3000, distinct=100, seed=2, curve=curve_name)
+    ctx = ea.MultiScalarMultContext(curve_name)
+    ctx.set_option("precompute", 2)
+    ctx.set_bases(small)
+    assert ctx.query("precompute") == 2 and ctx.query("table_levels") == 1 and ctx.query("table_window_bits") == 0
+    sc = rand_scalars_np(rid, 3000, 6)
+    assert ctx.run(sc)[0] == oracle_msm_np(oracle, cid, small, sc, 3000)
+    ctx.close()
+
+    n, distinct = 1 << 24, 1 << 12
+    tile = ea.generate_points(distinct, distinct=distinct, seed=8, curve=curve_name)
+    bases = torch.from_numpy(tile).cuda().repeat(n // distinct, 1).contiguous()
+    scal = torch.from_numpy(rand_scalars_np(rid, n, 9)).cuda()
+    plain = ea.MultiScalarMultContext(curve_name)
+    plain.set_bases(bases)
+    ref = plain.run(scal)[0]
+    k = 1 << 13
+    assert plain.run(scal[:k].contiguous(), npoints=k)[0] == oracle_msm_np(
+        oracle, cid, np.ascontiguousarray(np.tile(tile, (k // distinct, 1))), scal[:k].cpu().numpy(), k)
+    plain.close()
+    seen = []
+    ctx = ea.MultiScalarMultContext(curve_name)
+    ctx.set_option("precompute", 2)
+    for limit_gb in (0, 40, 24, 3):           # 0 = no limit: the whole (otherwise idle) device
+        ctx.set_option("mem_limit", limit_gb << 30)
+        ctx.set_bases(bases)
+        levels = ctx.query("table_levels")
+        seen.append(levels)
+        ctx.set_option("mem_limit", 0)
+        assert ctx.run(scal)[0] == ref, (limit_gb, levels)
+        assert ctx.last_timings()["tables"] == (levels > 1)
+    assert seen[0] >= 9 and seen[-1] == 1 and seen[0] >= seen[1] >= seen[2] >= seen[3], seen
+    assert any(1 < lv <= 6 for lv in seen), seen
+    # a build that fails although the estimate said it fits: back to no tables, not an error
+    ctx.set_option("inject_alloc_failures", 1)
+    ctx.set_bases(bases)
+    assert ctx.query("table_levels") == 1
+    assert ctx.run(scal)[0] == ref
+    ctx.close()
+
+
 def test_prefix_run_and_errors(ea, oracle, torch_cuda):
     c = m.BLS12_377_G1
     n = 600

@@ -190,3 +190,45 @@ def test_full_2_28_as_8_shards_of_2_25(ea, oracle):
     bases_np = np.ascontiguousarray(np.tile(tile_np, (k // distinct, 1)))
     exp = oracle_msm_np(oracle, 0, bases_np, sc_np, k)
     assert prefix_one == exp and prefix_sh == exp
+
+
+@pytest.mark.parametrize("curve,cid", [("bls12_377_g1", 0), ("bls12_377_g2", 2)])
+def test_peer_staging_branches_on_logical_shards(ea, oracle, curve, cid):
+    """The two code paths of a sharded context that pull a shard's slice out of ANOTHER device's memory -- the base staging of
+    sharded_set_bases and the per-batch scalar pull of sharded_run (csrc/msm_sharded.hpp) -- cannot be reached with logical shards
+    (the source always lies on the shard's own device), so they would first execute on the first multi-GPU box, under the driver's
+    clock.  The test hook "force_peer_staging" takes them on one GPU (the copies are then device-local; everything else is the peer
+    code): BASELINE configs[3]'s shape -- 8 shards, device-resident bases and scalars, a ragged size, two batches, a prefix run --
+    against the oracle, with the branch count asserted through mi355_msm_query "peer_stagings"."""
+    import ctypes
+
+    import torch
+
+    stride = ea.affine_stride(curve)
+    n = 8 * 1500 + 37
+    bases = ea.generate_points(n, distinct=400, seed=31, curve=curve)
+    sc = np.ascontiguousarray(np.random.default_rng(5).integers(0, 256, size=(2 * n, 32), dtype=np.uint8))
+    sc[:, 31] &= 0x0F
+    exp = []
+    for b in range(2):
+        out = ctypes.create_string_buffer(ea.projective_bytes(curve))
+        part = np.ascontiguousarray(sc[b * n:(b + 1) * n])
+        assert oracle.oracle_msm(cid, bases.ctypes.data, stride, part.ctypes.data, n, out, 0) == 0
+        exp.append(out.raw)
+    d_bases, d_sc = torch.from_numpy(bases).cuda(), torch.from_numpy(sc).cuda()
+    ctx = ea.MultiScalarMultContext(curve, devices=[0] * 8)
+    assert ctx.query("peer_stagings") == 0
+    ctx.set_bases(d_bases)
+    assert ctx.run(d_sc) == exp and ctx.query("peer_stagings") == 0        # the ordinary (own-device) branches
+    ctx.set_option("force_peer_staging", 1)
+    ctx.set_bases(d_bases)
+    assert ctx.query("peer_stagings") == 8                                   # one staged slice of bases per shard
+    assert ctx.run(d_sc) == exp
+    assert ctx.query("peer_stagings") == 16                                  # ... and one scalar pull per shard and run
+    k = 5 * 1500 + 3                                                         # a prefix: the last shards get nothing
+    out = ctypes.create_string_buffer(ea.projective_bytes(curve))
+    part = np.ascontiguousarray(sc[:k])
+    assert oracle.oracle_msm(cid, bases.ctypes.data, stride, part.ctypes.data, k, out, 0) == 0
+    assert ctx.run(d_sc[:k].contiguous(), npoints=k)[0] == out.raw
+    assert 16 < ctx.query("peer_stagings") <= 24
+    ctx.close()
