@@ -111,16 +111,76 @@ RustError guarded_dev(Fn&& fn) {
 // given back before any allocation is allowed to fail: returns true when something was freed.
 bool reclaim_idle_device_memory();
 
+// MI355_MSM_GUARD_TAIL = 1 (diagnostic; tests/test_gpu_guard.py): every device buffer of this library is placed so that it ENDS where
+// its mapping ends, with the address range behind it reserved but UNMAPPED (HIP virtual-memory API).  The hot kernels over-read by
+// design -- the entry queue of k_accumulate_glds fetches whole sectors past a lane's last entry, its LDS-DMA gathers fetch record 0 for
+// idle lanes -- and nothing but a slack convention (64 bytes behind the entry buffers) kept those reads inside an allocation; in this
+// mode a read or write past a buffer's last (16-byte-rounded) byte is a GPU memory fault instead of a silent access to a neighbour.
+// The reference keeps its only self-check disabled (CMB Partition4096.cu:419-432); device ASan cannot see the LDS-DMA intrinsic.
+struct GuardedRange {
+  void* va = nullptr;
+  size_t va_bytes = 0, mapped = 0;
+  hipMemGenericAllocationHandle_t handle{};
+};
+inline bool guard_tail_mode() {
+  static const bool on = [] {
+    const char* e = getenv("MI355_MSM_GUARD_TAIL");
+    return e && *e && atol(e) != 0;
+  }();
+  return on;
+}
+
 struct DevBuf {
   void* p = nullptr;
   size_t bytes = 0;
+  GuardedRange* guard = nullptr;
+  hipError_t guarded_alloc(size_t need) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    hipMemAllocationProp prop{};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = dev;
+    size_t gran = 0;
+    e = hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum);
+    if (e != hipSuccess) return e;
+    if (gran == 0) gran = (size_t)2 << 20;
+    const size_t used = (need + 15) & ~(size_t)15;
+    GuardedRange* g = new GuardedRange();
+    g->mapped = (used + gran - 1) / gran * gran;
+    g->va_bytes = g->mapped + gran;     // one granule behind the mapping stays unmapped: the guard
+    e = hipMemAddressReserve(&g->va, g->va_bytes, gran, nullptr, 0);
+    if (e == hipSuccess) {
+      e = hipMemCreate(&g->handle, g->mapped, &prop, 0);
+      if (e == hipSuccess) {
+        e = hipMemMap(g->va, g->mapped, 0, g->handle, 0);
+        if (e == hipSuccess) {
+          hipMemAccessDesc acc{};
+          acc.location = prop.location;
+          acc.flags = hipMemAccessFlagsProtReadWrite;
+          e = hipMemSetAccess(g->va, g->mapped, &acc, 1);
+          if (e != hipSuccess) (void)hipMemUnmap(g->va, g->mapped);
+        }
+        if (e != hipSuccess) (void)hipMemRelease(g->handle);
+      }
+      if (e != hipSuccess) (void)hipMemAddressFree(g->va, g->va_bytes);
+    }
+    if (e != hipSuccess) {
+      delete g;
+      return e;
+    }
+    guard = g;
+    p = (char*)g->va + (g->mapped - used);   // the buffer's last byte (rounded to 16) is the mapping's last byte
+    return hipSuccess;
+  }
   void reserve(size_t need) {
     if (need <= bytes) return;
     release();
-    hipError_t e = hipMalloc(&p, need);
+    hipError_t e = guard_tail_mode() ? guarded_alloc(need) : hipMalloc(&p, need);
     if (e == hipErrorOutOfMemory) {
       (void)hipGetLastError();
-      if (reclaim_idle_device_memory()) e = hipMalloc(&p, need);
+      if (reclaim_idle_device_memory()) e = guard_tail_mode() ? guarded_alloc(need) : hipMalloc(&p, need);
     }
     if (e != hipSuccess) {
       p = nullptr;
@@ -132,7 +192,15 @@ struct DevBuf {
     bytes = need;
   }
   void release() {
-    if (p) (void)hipFree(p);
+    if (guard) {
+      (void)hipMemUnmap(guard->va, guard->mapped);
+      (void)hipMemRelease(guard->handle);
+      (void)hipMemAddressFree(guard->va, guard->va_bytes);
+      delete guard;
+      guard = nullptr;
+    } else if (p) {
+      (void)hipFree(p);
+    }
     p = nullptr;
     bytes = 0;
   }
@@ -1755,6 +1823,8 @@ RustError mi355_msm_query(mi355_msm_ctx* ctx, const char* key, uint64_t* value) 
       *value = (uint64_t)ctx->opt_precompute;
     else if (k == "g2_paired")
       *value = (uint64_t)ctx->opt_g2_paired;
+    else if (k == "guard_tail")       // 1: MI355_MSM_GUARD_TAIL is on -- every device buffer ends at an unmapped page (DevBuf)
+      *value = guard_tail_mode() ? 1 : 0;
     else
       bad_arg("unknown query '%s'", key);
   });
