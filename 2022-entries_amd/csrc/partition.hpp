@@ -545,6 +545,8 @@ __global__ void __launch_bounds__(PART_THREADS) k_l1_scatter(const uint32_t* __r
       e.y &= 0xffffu;
 #ifdef PART_EXP_L1_NOSTORE   // diagnosis only (tools/group_probe.sh): everything but the global store
       if (e.x == 0x12345678u && e.y == 0x9abcu) out[0] = e;
+#elif defined(PART_EXP_L1_OUT4)   // diagnosis only (wrong output; profiles/r05_ab_group_compact.txt): 4-byte entries between level 1 and the pass --
+      reinterpret_cast<uint32_t*>(out)[offs[hi] + j] = e.x;   // the floor of ANY compact intermediate format (yrrid's is 5 bytes, CMB Partition1024.cu:157-243)
 #else
       out[offs[hi] + j] = e;
 #endif
@@ -654,6 +656,17 @@ __global__ void __launch_bounds__(1024) k_pass_subjobs(const PartSeg* __restrict
 #else
 #define PART_LD(e) (e)
 #endif
+// diagnosis only (wrong output): the pass READS 4-byte entries; the bits it partitions by are taken from the value so that the bins stay
+// uniformly filled
+#ifdef PART_EXP_PS_IN4
+__device__ __forceinline__ uint2 part_in(const uint2* __restrict__ in, uint32_t e) {
+  const uint32_t v = reinterpret_cast<const uint32_t*>(in)[e];
+  return make_uint2(v, (v * 2654435761u) >> 16);
+}
+#define PART_IN(in, e) part_in(in, e)
+#else
+#define PART_IN(in, e) ((in)[e])
+#endif
 // LDS of a scattering block: the staged tile, and per bin the cursor of the (sub-)job, the tile's count / first staged slot /
 // global position of its staged slot 0.
 struct PassLds {
@@ -673,7 +686,7 @@ __device__ __forceinline__ void pass_scatter_tiles(PassLds& L, const uint2* __re
 #pragma unroll
   for (int k = 0; k < PER; k++) {
     const uint32_t e = beg + threadIdx.x + k * 1024;
-    if (e < end) nxt[k] = in[PART_LD(e)];
+    if (e < end) nxt[k] = PART_IN(in, PART_LD(e));
   }
   // Barriers per tile: after the ranking (A), two inside the scan, after the scan step (B), after staging (C).  L.cnt is zeroed and
   // L.cur advanced IN the scan step, and there is no barrier at the end of a tile: the next tile's A orders its scan step (which
@@ -684,7 +697,7 @@ __device__ __forceinline__ void pass_scatter_tiles(PassLds& L, const uint2* __re
     for (int k = 0; k < PER; k++) {
       ent[k] = nxt[k];
       const uint32_t e = t0 + PART_PTILE + threadIdx.x + k * 1024;
-      if (e < end) nxt[k] = in[PART_LD(e)];
+      if (e < end) nxt[k] = PART_IN(in, PART_LD(e));
     }
     uint32_t where[PER];
 #pragma unroll
@@ -732,6 +745,8 @@ __device__ __forceinline__ void pass_scatter_tiles(PassLds& L, const uint2* __re
       if (e.x == 0x12345678u && e.y == 0x9abcu) out[0] = e;
 #elif defined(PART_EXP_PS_L2STORE)   // diagnosis only: the stores land in a 1-MB window (L2 hits, no HBM write traffic)
       out[(L.dst[bin] + j) & 0x1ffffu] = e;
+#elif defined(PART_EXP_PS_OUT4)      // diagnosis only (wrong output): the sorted output as 4-byte values (the key would come from a per-bucket offset table)
+      reinterpret_cast<uint32_t*>(out)[L.dst[bin] + j] = e.x;
 #else
       out[L.dst[bin] + j] = e;
 #endif
@@ -793,13 +808,13 @@ __global__ void __launch_bounds__(1024, PART_PASS_OCC) k_pass_scatter(const uint
     // four loads in flight per thread
     uint32_t e = beg + threadIdx.x;
     for (; e + 3 * 1024 < end; e += 4 * 1024) {
-      const uint32_t k0 = in[e].y, k1 = in[e + 1024].y, k2 = in[e + 2048].y, k3 = in[e + 3072].y;
+      const uint32_t k0 = PART_IN(in, e).y, k1 = PART_IN(in, e + 1024).y, k2 = PART_IN(in, e + 2048).y, k3 = PART_IN(in, e + 3072).y;
       atomicAdd(&L.cnt[(k0 >> shift) & (nb - 1)], 1u);
       atomicAdd(&L.cnt[(k1 >> shift) & (nb - 1)], 1u);
       atomicAdd(&L.cnt[(k2 >> shift) & (nb - 1)], 1u);
       atomicAdd(&L.cnt[(k3 >> shift) & (nb - 1)], 1u);
     }
-    for (; e < end; e += 1024) atomicAdd(&L.cnt[(in[e].y >> shift) & (nb - 1)], 1u);
+    for (; e < end; e += 1024) atomicAdd(&L.cnt[(PART_IN(in, e).y >> shift) & (nb - 1)], 1u);
   }
   lds_barrier();
   {
