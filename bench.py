@@ -279,7 +279,7 @@ def hbm_probe(torch, device, gib=4):
         return {"error": repr(e)}
 
 
-def stage_roofline(n, tm, ms, cid, geom):
+def stage_roofline(n, tm, ms, cid, geom, pmc_stages=None):
     """The HBM-bound stages against HBM: STRUCTURAL bytes each stage has to move once, over its measured time,
     as a fraction of the achievable streaming rate.  digits = level 1 of the grouping (scalars read twice, the tile x bin count
     matrix written once and read/written by the column scan and read by the scatter, the entries written); sort = the generic
@@ -299,6 +299,22 @@ def stage_roofline(n, tm, ms, cid, geom):
             out[k] = {"structural_bytes": b, "ms": ms[k], "GBps": gbps, "frac_of_achievable": gbps / HBM_ACHIEVABLE_GBPS}
     out["achievable_GBps"] = HBM_ACHIEVABLE_GBPS
     out["geometry"] = geom
+    if pmc_stages:
+        # the same stages from COUNTERS (profiles/<round>_pmc_k_accumulate*.json "stages": FETCH_SIZE / WRITE_SIZE per kernel of one bench step,
+        # measured on these kernel sources under this plan): what the kernels asked of the fabric, against the structural bytes above
+        by_stage = {}
+        for kern, row in pmc_stages.items():
+            d = by_stage.setdefault(row["stage"], {"hbm_bytes_estimate": 0.0, "kernel_ms": 0.0, "kernels": []})
+            d["hbm_bytes_estimate"] += row.get("hbm_bytes_estimate") or 0.0
+            d["kernel_ms"] += row.get("ms_per_step") or 0.0
+            d["kernels"].append(kern)
+            if row.get("valu_busy_fraction") is not None and kern in ("k_bucket_reduce", "k_pass_scatter", "k_l1_scatter"):
+                d["valu_busy_fraction"] = row["valu_busy_fraction"]
+        for k, d in by_stage.items():
+            if k in out and d["kernel_ms"]:
+                d["GBps"] = d["hbm_bytes_estimate"] / (d["kernel_ms"] * 1e-3) / 1e9
+                d["counter_over_structural_bytes"] = d["hbm_bytes_estimate"] / out[k]["structural_bytes"]
+                out[k]["counters"] = d
     return out
 
 
@@ -601,7 +617,7 @@ def quoted_pmc(E, tm, te_path, total_npow):
     counters need their own pass, so this run does NOT measure them: `traffic_from` says where the figure was measured, and it is only
     quoted when that pass ran on the very kernel sources this library was built from, under the very plan this run executes."""
     args = E.args
-    traffic = traffic_raw = traffic_from = valu = None
+    traffic = traffic_raw = traffic_from = valu = stages = None
     pmc_rel = os.path.join("profiles", "%s_pmc_k_accumulate%s.json" % (PMC_ROUND, {0: "", 1: "_381", 2: "_g2", 3: "_381g2"}[E.cid]))
     pmc_path = os.path.join(ROOT, pmc_rel)
     if (args.npow == (24 if E.cid >= 2 else 26) and not total_npow and not args.window_bits and not args.lane_entries and not args.precompute
@@ -625,9 +641,10 @@ def quoted_pmc(E, tm, te_path, total_npow):
             valu = {"busy_fraction": pmc["derived"]["valu_busy_fraction"], "effective_clock_GHz": pmc["derived"]["effective_clock_GHz"],
                     "valu_instr_per_mixed_add": pmc["derived"]["valu_instr_per_mixed_add"], "from": pmc_rel,
                     "note": "counters of the committed profile's box; THIS run's clock is config.clock_MHz_*"}
+            stages = pmc.get("stages")
         else:
             traffic_from = f"not quoted: {pmc_rel} was measured on kernel sources {pmc.get('kernel_source_sha16')}, this library is built from {sha}"
-    return traffic, traffic_raw, traffic_from, valu
+    return traffic, traffic_raw, traffic_from, valu, stages
 
 
 def main():
@@ -874,7 +891,7 @@ def main():
         kern_s = (acc_ms / max(acc_launches, 1)) * 1e-3
         pairs_per_launch = n * args.steps / max(acc_launches, 1)
         achieved = BYTES_PER_PAIR[cid] * pairs_per_launch / kern_s / 1e9
-        traffic, traffic_raw, traffic_from, valu = quoted_pmc(E, tm, ctx_te_path, total_npow)
+        traffic, traffic_raw, traffic_from, valu, pmc_stages = quoted_pmc(E, tm, ctx_te_path, total_npow)
         # the integer roofline: lane-level v_mad_u64_u32 per second in the dominant kernel against the measured
         # issue peak of 1024 SIMDs x 64 lanes / 4.3 cycles at the nominal 2.4 GHz (profiles/r01_ubench_valu_*.txt).
         # v_mad_u64_u32 per mixed addition: a property of the formulas, pinned on the generated ISA by tests/test_isa.py -- 7 multiplications
@@ -928,7 +945,7 @@ def main():
                                        f"{'RCCL all-gather' if ctx_rccl else 'host fold'} of {args.gpus} partial points" if c_sharded else
                                        f"{world} disjoint base/scalar slices + all-gather of {world} partial points")},
             "stage_ms_per_step": {k: v / args.steps for k, v in stage_ms.items()},
-            "stage_roofline": stage_roofline(n, tm, {k: v / args.steps for k, v in stage_ms.items()}, cid, geom) if geom else None,
+            "stage_roofline": stage_roofline(n, tm, {k: v / args.steps for k, v in stage_ms.items()}, cid, geom, pmc_stages) if geom else None,
             "per_rank": per_rank,
             "weak_scaling_point": weak_point,
             "roofline": {"bound": "hbm", "kernel": "k_accumulate_glds", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",

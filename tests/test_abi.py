@@ -126,3 +126,40 @@ def test_execution_plan_is_sane_and_terminates(ea):
         ea.plan(100, seg_entries=2)
     with pytest.raises(ea.MsmError):
         ea.plan(100, window_bits=99)
+
+
+def test_plan_with_table_levels(ea):
+    """The plan of a context with "table_levels" = k (the query used to assume a level per window): k levels over
+    ceil(windows / k) bucket sets, levels rounded so that none is empty (13 windows in 6 levels are 3 sets x 5 levels), the reference's
+    own shape -- 6 levels, 2 bucket sets (CMB PrecomputePoints.cu:10-39, MSM.cu:380-383) -- at 2^26 pairs, and less work memory for
+    fewer bucket sets."""
+    for curve in ("bls12_377_g1", "bls12_381_g1", "bls12_377_g2"):
+        for npow in (14, 20, 26):
+            every = ea.plan(1 << npow, curve, precompute=True)
+            for k in (2, 3, 6, 40):
+                p = ea.plan(1 << npow, curve, precompute=True, table_levels=k)
+                levels = -(-p["windows"] // p["bucket_windows"])
+                assert p["window_bits"] * p["windows"] >= 257 and levels <= k and p["bucket_windows"] == -(-p["windows"] // min(k, p["windows"]))
+                assert (p["bucket_windows"] << (p["window_bits"] - 1)) < 1 << p["key_bits"]
+                if k == 40:
+                    assert p == every          # more levels than windows: a level per window
+    p = ea.plan(1 << 26, precompute=True, table_levels=6)
+    assert p["window_bits"] == 23 and p["windows"] == 12 and p["bucket_windows"] == 2
+    with pytest.raises(ValueError):
+        ea.plan(100, precompute=True, table_levels=1)
+
+
+def test_bench_telemetry_never_raises_without_a_gpu():
+    """bench.py samples the GPU's clock and power in a thread during the timed loop (sysfs hwmon, then amdsmi); on a box without
+    either -- this container -- it must say so in `telemetry_source` and report None, never fail the line."""
+    import bench
+
+    t = bench.Telemetry(0)
+    t.start()
+    r = t.stop()
+    assert set(r) == {"clock_MHz_mean", "clock_MHz_min", "clock_MHz_max", "power_W_mean", "power_W_max", "samples"}
+    if t.source is None:
+        assert r["clock_MHz_mean"] is None and r["samples"] == 0 and t.describe().startswith("unavailable")
+    probe = bench.ark_ec_probe(10)
+    assert probe["available"] in (False, True) and ("probe" in probe or "error" in probe or probe.get("kind") == "ark-ec")
+    assert len(bench.kernel_source_sha16()) == 16

@@ -7,7 +7,7 @@ configs[3], four times the single-GPU problem over eight shards, plus the weak-s
 report, the max-over-ranks timing, the one JSON line on rank 0 -- is the code the driver will execute.  Round 3 shipped an N = 8
 line that raised before printing (a query on a closed context); this test is what would have caught it.
 
-The lines are kept under gpurun_out/ (copied to profiles/r04_bench_rehearsal_*.json).
+The lines are kept under gpurun_out/ (copied to profiles/r05_bench_rehearsal_*.json).
 """
 import json
 import os
@@ -33,7 +33,7 @@ def _keep(name: str, line: dict) -> None:
     d = os.path.join(ROOT, "gpurun_out")
     try:
         os.makedirs(d, exist_ok=True)
-        with open(os.path.join(d, f"r04_bench_rehearsal_{name}.json"), "w") as f:
+        with open(os.path.join(d, f"r05_bench_rehearsal_{name}.json"), "w") as f:
             json.dump(line, f, indent=1)
     except OSError:
         pass

@@ -73,7 +73,7 @@ def test_debug_build_holds_its_invariants_on_all_curves(built):
     assert set(checks) == {"bls12_377_g1", "bls12_381_g1", "bls12_377_g2", "bls12_381_g2"}
     d = os.path.join(ROOT, "gpurun_out")
     os.makedirs(d, exist_ok=True)
-    with open(os.path.join(d, "r04_debug_build_checks.json"), "w") as f:
+    with open(os.path.join(d, "r05_debug_build_checks.json"), "w") as f:
         json.dump(checks, f, indent=1)
 
 

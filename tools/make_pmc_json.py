@@ -54,6 +54,45 @@ def headline_counters(tag):
     return out
 
 
+def stage_counters():
+    """Counters of the HBM-bound stage kernels of the same bench step (stage_roofline on counters, not on structural-byte
+    arithmetic alone): per kernel name, every counter summed over the step's launches of that kernel, plus its time in the kernel trace."""
+    want = {"k_l1_hist": "digits", "k_l1_scan": "digits", "k_l1_scatter": "digits", "k_pass_hist": "sort", "k_pass_scan": "sort", "k_pass_scatter": "sort",
+            "k_bucket_reduce": "bucket_reduce"}
+    per = {}
+    for tag in ("FETCH_SIZE", "WRITE_SIZE", "SQ_WAVES_SQ_INSTS_VALU_SQ_WAVE_CYCLES_SQ_BUSY_CYCLES", "SQ_ACTIVE_INST_VALU_SQ_WAIT_INST_ANY_SQ_WAIT_ANY_SQ_ACTIVE_INST_ANY",
+                "GRBM_GUI_ACTIVE"):
+        for f in glob.glob(os.path.join(prof, "pmc_" + tag, "**", "*counter_collection.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                name = r.get("Kernel_Name", "")
+                for k in want:
+                    if k in name:
+                        d = per.setdefault(k, {})
+                        d[r["Counter_Name"]] = d.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+    # time: the kernel-trace pass ran `steps` timed steps + warm-up: average per step = total / number of k_accumulate launches of the headline grid
+    for f in glob.glob(os.path.join(prof, "stats", "**", "*kernel_trace.csv"), recursive=True):
+        rows = list(csv.DictReader(open(f)))
+        steps = sum(1 for r in rows if "k_accumulate" in r["Kernel_Name"] and int(r["Grid_Size_X"]) == c.get("lanes")) or 1
+        for r in rows:
+            for k in want:
+                if k in r["Kernel_Name"]:
+                    per.setdefault(k, {})
+                    per[k]["ms_per_step"] = per[k].get("ms_per_step", 0.0) + (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 / steps
+    out = {}
+    for k, d in per.items():
+        row = {"stage": want[k], "ms_per_step": d.get("ms_per_step"), "FETCH_SIZE_KiB": d.get("FETCH_SIZE"), "WRITE_SIZE_KiB": d.get("WRITE_SIZE")}
+        # coalesced streams: FETCH_SIZE tallies 64 B per request while a request carries 128 B (calibration: 0.500); the scattered 8-byte-entry
+        # runs of the grouping are written as whole 64 / 128-B runs (WRITE_SIZE exact for coalesced stores)
+        if d.get("FETCH_SIZE") is not None and d.get("WRITE_SIZE") is not None:
+            row["hbm_bytes_estimate"] = d["FETCH_SIZE"] * 1024.0 / 0.5 + d["WRITE_SIZE"] * 1024.0
+            if d.get("ms_per_step"):
+                row["GBps"] = row["hbm_bytes_estimate"] / (d["ms_per_step"] * 1e-3) / 1e9
+        if d.get("SQ_ACTIVE_INST_VALU") and d.get("GRBM_GUI_ACTIVE"):
+            row["valu_busy_fraction"] = d["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / (d["GRBM_GUI_ACTIVE"] / 8)
+        out[k] = row
+    return out
+
+
 c = {}
 for tag in ("FETCH_SIZE", "WRITE_SIZE", "SQ_WAVES_SQ_INSTS_VALU_SQ_WAVE_CYCLES_SQ_BUSY_CYCLES", "SQ_ACTIVE_INST_VALU_SQ_WAIT_INST_ANY_SQ_WAIT_ANY_SQ_ACTIVE_INST_ANY",
             "GRBM_GUI_ACTIVE"):
@@ -121,6 +160,10 @@ res = {
     "SQ_WAIT_INST_ANY_quad": c.get("SQ_WAIT_INST_ANY"), "SQ_WAIT_ANY_quad": c.get("SQ_WAIT_ANY"), "GRBM_GUI_ACTIVE": c.get("GRBM_GUI_ACTIVE"),
     "kernel_ms_rocprof": kern_ms, "lanes": c.get("lanes"),
     "derived": {},
+    "stages": stage_counters(),
+    "stages_note": "per-kernel counters of the grouping and bucket-reduction kernels in the same passes (one bench step): FETCH_SIZE / WRITE_SIZE as "
+                   "reported (KiB), hbm_bytes_estimate = FETCH_SIZE / 0.5 + WRITE_SIZE (these kernels read coalesced streams, which gfx950 counts at "
+                   "64 B per 128-B request: tools/calib_fetch.hip); bench.py's stage_roofline quotes them next to its structural-byte figures",
 }
 if kern_ms and c.get("GRBM_GUI_ACTIVE"):
     res["derived"]["effective_clock_GHz"] = c["GRBM_GUI_ACTIVE"] / 8 / (kern_ms * 1e-3) / 1e9
