@@ -430,6 +430,23 @@ __global__ void __launch_bounds__(256, G::ACC_WAVES) k_bucket_reduce(const XyzzD
   bool bad = false;
   G::set_identity(run);
   G::set_identity(wsum);
+#ifndef MSM_REDUCE_PREFETCH
+#define MSM_REDUCE_PREFETCH 0   // A/B (profiles/r05_ab_reduce_prefetch.txt): 1 = the next bucket is loaded before the two additions of the current one
+#endif
+#if MSM_REDUCE_PREFETCH
+  XyzzT<typename G::T> v_next;
+  if (hi > lo) v_next = G::load_pt(x + hi - 1, half);
+  for (uint32_t j = hi; j-- > lo;) {
+    const XyzzT<typename G::T> v = v_next;
+    if (j > lo) v_next = G::load_pt(x + j - 1, half);
+    G::add(run, v, md);
+    if (G::CHECKS) bad |= G::failed(run);
+    if (FIRST || j > lo) {
+      G::add(wsum, run, md);
+      if (G::CHECKS) bad |= G::failed(wsum);
+    }
+  }
+#else
   for (uint32_t j = hi; j-- > lo;) {
     const XyzzT<typename G::T> v = G::load_pt(x + j, half);
     G::add(run, v, md);
@@ -439,6 +456,7 @@ __global__ void __launch_bounds__(256, G::ACC_WAVES) k_bucket_reduce(const XyzzD
       if (G::CHECKS) bad |= G::failed(wsum);
     }
   }
+#endif
   if (!FIRST) {
     const XD* a = in_a + (size_t)w * n_per_win;
     for (uint32_t j = lo; j < hi; j++) {
