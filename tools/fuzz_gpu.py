@@ -14,9 +14,10 @@ lib.oracle_msm.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctype
 CURVES = [("bls12_377_g1", 0, 0x12ab655e9a2ca556), ("bls12_381_g1", 1, 0x73eda753299d7d48), ("bls12_377_g2", 2, 0x12ab655e9a2ca556), ("bls12_381_g2", 3, 0x73eda753299d7d48)]
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+G2_MIX = [2, 2, 2, 3, 3, 3, 0, 1]     # argv[3] == "g2": mostly G2 cases (the paired kernels)
 bad = 0
 for case in range(cases):
-    name, cid, top = CURVES[rng.choice([0, 0, 0, 1, 1, 1, 2, 3])]
+    name, cid, top = CURVES[rng.choice(G2_MIX if len(sys.argv) > 3 and sys.argv[3] == "g2" else [0, 0, 0, 1, 1, 1, 2, 3])]
     n = rng.choice([1, 2, 5, 31, 32, 33, 100, 257, 1023, 1024, 3000, 8191, 8193, 9999, 40000, 70001, 200000])
     if cid >= 2:
         n = min(n, 3000)
@@ -59,6 +60,8 @@ for case in range(cases):
         opts["precompute"] = 1
         if rng.random() < 0.6:
             opts["table_levels"] = rng.choice([2, 3, 4, 6, 9])      # round 4: k levels, ceil(W / k) bucket sets
+    elif rng.random() < 0.1:
+        opts["precompute"] = 2                                      # round 5: auto (no tables at these sizes: the option must be inert)
     if rng.random() < 0.5:
         opts["window_bits"] = rng.randrange(2, 25) if rng.random() < 0.3 else rng.randrange(2, 18)
     if cid == 0 and rng.random() < 0.25:
@@ -79,6 +82,15 @@ for case in range(cases):
         ctx.set_option("carry", 0); opts["carry"] = 0          # chunks reduce their own buckets (the default carries one bucket array)
     if special == "" and rng.random() < 0.3:
         ctx.set_option("assume_subgroup", 1); opts["fold"] = 1  # the generator's points are multiples of G: scalars above r/2 fold
+    if cid >= 2 and rng.random() < 0.7:
+        # round 5: which G2 throughput kernels run two lanes per point (csrc/fp2pair.hpp); quad_limit = 0 sends the merge and scan
+        # launches of these small inputs through them at all
+        opts["g2_paired"] = rng.choice([0, 1, 2, 4, 8, 16, 31, rng.randrange(32)])
+        ctx.set_option("g2_paired", opts["g2_paired"])
+        if rng.random() < 0.6:
+            ctx.set_option("quad_limit", 0); opts["quad"] = 0
+    if shards and rng.random() < 0.4:
+        ctx.set_option("force_peer_staging", 1); opts["peer"] = 1   # round 5: the cross-device staging branches of a sharded context
     got = ctx.run(torch.from_numpy(sc).cuda() if rng.random() < 0.5 else sc)[0]
     ctx.close()
     if rng.random() < 0.15 and not shards:
