@@ -217,8 +217,9 @@ class MultiScalarMultContext:
 
     @classmethod
     def from_env(cls, curve="bls12_377_g1") -> "MultiScalarMultContext":
-        """What the harness shims do: honour MI355_MSM_DEVICES ("0,1,2,3", "0-7", "all"; unset = the current device) and
-        MI355_MSM_ASSUME_SUBGROUP (0 | 1: the context option of that name)."""
+        """What the harness shims do: honour MI355_MSM_DEVICES ("0,1,2,3", "0-7", "all"; unset = the current device),
+        MI355_MSM_ASSUME_SUBGROUP (0 | 1: the context option of that name) and MI355_MSM_PRECOMPUTE (auto | 1 | 0) /
+        MI355_MSM_TABLE_LEVELS (options "precompute" / "table_levels")."""
         self = cls.__new__(cls)
         self.curve = _curve_id(curve)
         self._lib = load_library()

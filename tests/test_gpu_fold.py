@@ -118,6 +118,35 @@ def test_environment_switch_for_harness_contexts(ea, oracle, monkeypatch):
         ctx.close()
 
 
+def test_environment_switch_for_precompute(ea, oracle, monkeypatch):
+    """MI355_MSM_PRECOMPUTE = auto | 1 | 0 and MI355_MSM_TABLE_LEVELS through mi355_msm_create_env (the harness shims' constructor):
+    the reference's init builds its tables untimed (CMB MSM.cu:380-383), a harness that owns the GPU opts in through the environment."""
+    curve = m.BLS12_377_G1
+    n = 5000
+    bases = ea.generate_points(n, distinct=77, seed=3, curve=curve.name)
+    sc = np.frombuffer(m.encode_scalars([k % curve.r for k in _scalars_with_edges(curve, n, 4)]), dtype=np.uint8).reshape(n, 32)
+    sc = np.ascontiguousarray(sc)
+    exp = oracle_msm_np(oracle, 0, bases, sc, n)
+    for pre, levels, want_pre, want_tables in ((None, None, 0, False), ("auto", None, 2, False), ("1", "3", 1, True), ("0", None, 0, False)):
+        for k, v in (("MI355_MSM_PRECOMPUTE", pre), ("MI355_MSM_TABLE_LEVELS", levels)):
+            if v is None:
+                monkeypatch.delenv(k, raising=False)
+            else:
+                monkeypatch.setenv(k, v)
+        ctx = ea.MultiScalarMultContext.from_env(curve.name)
+        assert ctx.query("precompute") == want_pre
+        ctx.set_bases(bases)
+        assert (ctx.query("table_levels") > 1) == want_tables       # (auto builds none for an input this small)
+        if want_tables:
+            assert ctx.query("table_levels") <= 3
+        assert ctx.run(sc)[0] == exp
+        ctx.close()
+    monkeypatch.setenv("MI355_MSM_PRECOMPUTE", "auto")
+    monkeypatch.setenv("MI355_MSM_TABLE_LEVELS", "999")
+    with pytest.raises(ea.MsmError):
+        ea.MultiScalarMultContext.from_env(curve.name)
+
+
 @pytest.mark.parametrize("cid,curve", CURVES)
 def test_every_scalar_folded_and_sharded_contexts(ea, oracle, cid, curve):
     """All scalars in (r/2, r) -- every one of them runs as (r - k)(-P) -- and none (all below r/2); tiny inputs; a sharded context
