@@ -780,7 +780,8 @@ bool build_tables_te_streamed(mi355_msm_ctx* ctx, const uint8_t* d_raw, size_t n
       // keep level 0 of the short-Weierstrass form only: it serves the (rare) XYZZ fallback, without tables
       DevBuf level0;
       level0.reserve(n * sizeof(AffineDev));
-      HIP_OK(hipMemcpy(level0.p, ctx->bases.p, n * sizeof(AffineDev), hipMemcpyDeviceToDevice));
+      HIP_OK(hipMemcpyAsync(level0.p, ctx->bases.p, n * sizeof(AffineDev), hipMemcpyDeviceToDevice, st));
+      HIP_OK(hipStreamSynchronize(st));   // (a device-to-device hipMemcpy is not host-synchronous: the source is freed next)
       ctx->bases.release();
       ctx->bases = level0;
     }

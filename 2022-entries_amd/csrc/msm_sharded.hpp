@@ -227,7 +227,11 @@ static void sharded_set_bases(mi355_msm_ctx* ctx, const void* data, size_t n, si
     DevBuf stage;
     try {
       stage.reserve(cnt * stride);
-      HIP_OK(hipMemcpy(stage.p, src, cnt * stride, hipMemcpyDefault));
+      // ON THE SHARD'S STREAM: a device-to-device hipMemcpy is not synchronous with the host and lives on the null stream, which the
+      // shard's non-blocking stream does not wait for -- the conversion kernel read the staging buffer before the copy had landed
+      // (found by tests/test_gpu_sharded.py::test_peer_staging_branches_on_logical_shards in round 5, on the first box where the
+      // timing exposed it: this branch had never executed before the "force_peer_staging" hook existed)
+      HIP_OK(hipMemcpyAsync(stage.p, src, cnt * stride, hipMemcpyDefault, sh->own_stream));
       set_bases_device(sh, stage.p, cnt, stride);
     } catch (...) {
       stage.release();
