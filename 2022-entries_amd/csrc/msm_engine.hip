@@ -1403,7 +1403,9 @@ void set_bases_host(mi355_msm_ctx* ctx, const void* affine, size_t npoints, size
   try {
     if (npoints) {
       raw.reserve(npoints * stride);
-      HIP_OK(hipMemcpy(raw.p, affine, npoints * stride, hipMemcpyHostToDevice));
+      // (on the context's stream, like everything that follows: nothing here relies on what a null-stream copy does or does not order
+      //  against a non-blocking stream -- the lesson of the staging race in msm_sharded.hpp)
+      HIP_OK(hipMemcpyAsync(raw.p, affine, npoints * stride, hipMemcpyHostToDevice, ctx->own_stream));
     }
     set_bases_device(ctx, raw.p, npoints, stride);
   } catch (...) {
