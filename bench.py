@@ -474,6 +474,20 @@ def measure_secondary_configs(E):
                          "roofline_frac_hbm": BYTES_PER_PAIR[cid2] * n2 / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
             if cid2 >= 2:
                 sec[name]["g2_paired"] = c2.query("g2_paired")   # bit mask of the kernels that run two lanes per point (csrc/fp2pair.hpp)
+            if cname == "bls12_377_g2":
+                # BASELINE configs[4] once more with "precompute" = 2 (auto: tables from the free HBM, init untimed): non-default, reported beside
+                c2.close()
+                c2 = ea.MultiScalarMultContext(cname, device=E.local_rank)
+                c2.set_option("precompute", 2)
+                t_i = time.perf_counter()
+                c2.set_bases(tile2.repeat(n2 // E.distinct, 1).contiguous())
+                torch.cuda.synchronize()
+                t_i = time.perf_counter() - t_i
+                ms3, _ = timed(lambda: c2.run(sc2)[0], 3)
+                tm3 = c2.last_timings()
+                sec[name]["with_precompute_auto"] = {"ms_per_step": ms3, "table_levels": c2.query("table_levels"), "window_bits": tm3["window_bits"],
+                                                     "table_bytes": c2.query("base_bytes"), "init_s": t_i,
+                                                     "stage_ms": {k: tm3[k] for k in ("digits", "sort", "accumulate", "segreduce", "bucket_reduce")}}
             del tile2, sc2
         except Exception as e:
             sec[name] = {"error": repr(e)}
