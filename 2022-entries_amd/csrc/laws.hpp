@@ -7,9 +7,6 @@
 //   Base/BaseDev (what a lane gathers), set_identity, begin_run(acc) at every change of key, madd(acc, base, negate, fresh), add(acc, b) where b may be an
 //   all-zero "empty" record (a bucket nobody wrote), mul_pow2(acc, k), and failed(acc): true when the law could not
 //   compute the last result (TeLaw only: a vanishing denominator off the odd-order subgroup) -- kernels raise a flag then.
-//   SwPairLaw<F, NB> (round 5)  G2 with every Fp2 value on TWO neighbouring lanes (fp2pair.hpp): LANES = 2, T = Fe (what a lane holds),
-//   MemT = Fe2 (what the records in memory hold); load_pt / store_pt / from_dev_lane / load_sectors take the lane's half.  The
-//   one-lane laws have LANES = 1 and MemT = T, so the kernels of msm_kernels.hpp are written once for both.
 #pragma once
 #include "curve.hpp"
 #include "fp2pair.hpp"
