@@ -503,19 +503,22 @@ MSM_HD void xyzz_add(XyzzT<typename E::T>& acc, const XyzzT<typename E::T>& b, c
 //   4   S1 PPP      | R (Q - X3)   | --          | ZZZ3 = (ZZZ1 ZZZ2) PPP;   X3 = RR - PPP - 2Q,  Y3 = R (Q - X3) - S1 PPP
 // Same bounds as xyzz_add / add_tail.  Infinity operands and the same-x cases (doubling, cancellation) are decided
 // quad-uniformly; the doubling -- rare -- gathers the point and runs the one-lane formula on every lane.
-template <int CTRL>
+template <int CTRL, int N = NL>
 __device__ __forceinline__ void fe_quad_perm(Fe& r, const Fe& a) {
 #pragma unroll
-  for (int i = 0; i < NL; i++) r.v[i] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a.v[i], CTRL, 0xf, 0xf, true);
+  for (int i = 0; i < N; i++) r.v[i] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a.v[i], CTRL, 0xf, 0xf, true);
+#pragma unroll
+  for (int i = N; i < NL; i++) r.v[i] = 0;
 }
 template <int CTRL>
 __device__ __forceinline__ bool quad_flag(bool z) {   // one lane's flag to the whole quad (CTRL = 0x00 / 0x55 / 0xAA / 0xFF: lane 0..3)
   return __builtin_amdgcn_update_dpp(0, (int)z, CTRL, 0xf, 0xf, true) != 0;
 }
+template <int N = NL>
 __device__ __forceinline__ void fe_select(Fe& r, const Fe& a, const Fe& b, bool take_b) {   // r = take_b ? b : a
   const LaneMask m = lane_mask(take_b);
   r = a;
-  fe_cmov(r, b, m);
+  fe_cmov<N>(r, b, m);
 }
 // the same two helpers for Fp2 coordinates
 template <int CTRL>

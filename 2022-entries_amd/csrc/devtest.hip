@@ -161,13 +161,35 @@ hipError_t launch_op(int op, const uint32_t* d_in, int in_words, uint32_t* d_out
   return hipErrorInvalidValue;
 }
 
+// the op subset of the 13 x 29 shape (devtest_ops.hpp: DT_CURVE_TE29)
+inline hipError_t launch_op_te29(int op, const uint32_t* d_in, int in_words, uint32_t* d_out, int out_words, uint32_t n) {
+  using C = Bls12_377_G1_29;
+  switch (op) {
+#define DT_CASE(OP) case OP: return launch_one<C, OP>(d_in, in_words, d_out, out_words, n);
+    DT_CASE(DT_FE_MUL)
+    DT_CASE(DT_TE_MADD)
+    DT_CASE(DT_TE_MADD_SWAPPED)
+    DT_CASE(DT_TE_ADD)
+    DT_CASE(DT_TE_DBL)
+    DT_CASE(DT_TE_ADD_QUAD)
+#undef DT_CASE
+    default: break;
+  }
+  return hipErrorInvalidValue;
+}
+
 }  // namespace msm
 
 extern "C" {
 
 // words per input / output record of `op` on `curve` (0/0 for an op the curve does not have)
 int msm_devtest_shape(int curve, int op, int* in_words, int* out_words) {
-  if (!in_words || !out_words || curve < 0 || curve > 3) return -1;
+  if (!in_words || !out_words || curve < 0 || curve > msm::DT_CURVE_TE29) return -1;
+  if (curve == msm::DT_CURVE_TE29) {
+    *in_words = *out_words = 0;
+    if (msm::dt_op_in_te29(op)) msm::devtest_shape(op, msm::NL, *in_words, *out_words);
+    return (*in_words) ? 0 : -1;
+  }
   if (op >= msm::DT_PAIR) {   // the two-lanes-per-record form of a G2 op: same records
     op -= msm::DT_PAIR;
     if (curve < 2 || op < msm::DT_EL_MUL || op > msm::DT_DBL) return -1;
@@ -188,7 +210,9 @@ int msm_devtest_run(int curve, int op, const uint32_t* in, uint32_t* out, size_t
   if (e == hipSuccess) e = hipMalloc(&d_out, n * ow * 4);
   if (e == hipSuccess) e = hipMemcpy(d_in, in, n * iw * 4, hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemset(d_out, 0xEE, n * ow * 4);
-  if (e == hipSuccess && op >= msm::DT_PAIR) {
+  if (e == hipSuccess && curve == msm::DT_CURVE_TE29) {
+    e = msm::launch_op_te29(op, d_in, iw, d_out, ow, (uint32_t)n);
+  } else if (e == hipSuccess && op >= msm::DT_PAIR) {
     e = curve == 2 ? msm::launch_pair_op<msm::Bls12_377_G2>(op - msm::DT_PAIR, d_in, iw, d_out, ow, (uint32_t)n)
                    : msm::launch_pair_op<msm::Bls12_381_G2>(op - msm::DT_PAIR, d_in, iw, d_out, ow, (uint32_t)n);
   } else if (e == hipSuccess) {

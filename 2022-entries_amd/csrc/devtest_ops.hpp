@@ -60,6 +60,14 @@ MSM_HD void devtest_shape(int op, int EW, int& in_words, int& out_words) {
   }
 }
 
+// "curve" id 4 of the test libraries: BLS12-377 Fq in its 13 x 29 limb shape (fp28.hpp) -- FE_MUL and the twisted-Edwards ops only.
+// Records keep 14 words per field element (word 13 is 0), exactly as the kernels hold them.
+struct Bls12_377_G1_29 {
+  using E = FpEl<Bls12_377_Fq29>;
+};
+constexpr int DT_CURVE_TE29 = 4;
+MSM_HD bool dt_op_in_te29(int op) { return op == DT_FE_MUL || (op >= DT_TE_MADD && op <= DT_TE_DBL) || op == DT_TE_ADD_QUAD; }
+
 template <class T>
 MSM_HD void dt_load(T& r, const uint32_t* w) {
   uint32_t* d = reinterpret_cast<uint32_t*>(&r);

@@ -21,6 +21,14 @@
 //   "normalized": v[0..12] < 2^28 (v[13] holds what is left).
 //   mul inputs: every limb < 2^30 and value(a)*value(b) <= 2^10 p^2 (e.g. both values < 32p).
 //   class M ("mul output"): normalized, value < p + a*b/R < 1.5p  (2^10 p^2 / 2^392 < p/2 for p < 2^381).
+//
+// A second limb shape, per FIELD (the constants struct F carries N = limbs in use, B = bits per limb, NRED = Montgomery steps):
+// BLS12-377's 377 bits are 13 x 29, and Bls12_377_Fq29 runs fe_mul on 13 limbs with 14 reduction steps (R = 2^406) -- 169 + 168 = 337
+// multiply-adds instead of 196 + 182 = 378.  The 14th step is not optional: with R = 2^377, p/R = 0.84 and the product of two lazily
+// reduced operands (3p x 4p) comes out at 11p, not < 2p.  A column of 13 a*b + 13 m*p terms fits 64 bits only while
+// 13 * limb_a * limb_b < 51 * 2^58, i.e. one bit less slack than 14 x 28 has: the twisted-Edwards law (te.hpp) pays for it with two
+// carry passes per addition (tools/limb_bounds29.py proves the column bounds, MSM_CHECK builds check them on every product).
+// Fe keeps 14 words either way (word 13 of a 13-limb value is 0), so records in memory and every kernel are shared.
 #pragma once
 #include <stdint.h>
 
@@ -152,16 +160,18 @@ MSM_HD void mad_chain(uint64_t& col, const uint32_t (&x)[NL], const uint32_t (&y
 #endif
 }
 
-// ~x & LMASK in one instruction (v_bfi_b32 D = (S0 & S1) | (~S0 & S2) with S1 = 0): hipcc would emit v_not + v_and
-MSM_HD uint32_t not_and_lmask(uint32_t x) {
+// ~x & MASK in one instruction (v_bfi_b32 D = (S0 & S1) | (~S0 & S2) with S1 = 0): hipcc would emit v_not + v_and
+template <uint32_t MASK>
+MSM_HD uint32_t not_and_mask(uint32_t x) {
 #if defined(__HIP_DEVICE_COMPILE__)
   uint32_t d;
-  asm("v_bfi_b32 %0, %1, 0, %2" : "=v"(d) : "v"(x), "s"(LMASK));
+  asm("v_bfi_b32 %0, %1, 0, %2" : "=v"(d) : "v"(x), "s"(MASK));
   return d;
 #else
-  return ~x & LMASK;
+  return ~x & MASK;
 #endif
 }
+MSM_HD uint32_t not_and_lmask(uint32_t x) { return not_and_mask<LMASK>(x); }
 
 // The Montgomery step of column k: col += m_k * p_0 (which clears the low limb), then shift the column down.
 // When p = 1 (mod 2^28) -- BLS12-377, whose p - 1 is divisible by 2^46 -- m_k = -col mod 2^28 and p_0 = 1, so
@@ -171,78 +181,98 @@ MSM_HD uint32_t not_and_lmask(uint32_t x) {
 // MK_FROM_COL: the caller has not computed m_k yet (the p_0 = 1 path derives it here; otherwise it is (col * M0) & LMASK).
 #define MSM_MONT_STEP(F, col, mk, md)                                              \
   do {                                                                             \
+    constexpr uint32_t FM_ = (1u << F::B) - 1;                                     \
     if (F::P[0] == 1) {                                                            \
-      const uint64_t s_ = (col) + LMASK;                                           \
-      (mk) = not_and_lmask((uint32_t)s_);                                          \
-      MSM_CHECK((mk) == ((0u - (uint32_t)(col)) & LMASK));                         \
+      const uint64_t s_ = (col) + FM_;                                             \
+      (mk) = not_and_mask<FM_>((uint32_t)s_);                                      \
+      MSM_CHECK((mk) == ((0u - (uint32_t)(col)) & FM_));                           \
       MSM_CHECK_COL_ADD(mk);                                                       \
       MSM_CHECK_COL_END((col) + (mk));                                             \
-      MSM_CHECK((((col) + (mk)) & LMASK) == 0 && (((col) + (mk)) >> LB) == (s_ >> LB)); \
-      (col) = s_ >> LB;                                                            \
+      MSM_CHECK((((col) + (mk)) & FM_) == 0 && (((col) + (mk)) >> F::B) == (s_ >> F::B)); \
+      (col) = s_ >> F::B;                                                          \
     } else {                                                                       \
-      (mk) = ((uint32_t)(col) * F::M0) & LMASK;                                    \
+      (mk) = ((uint32_t)(col) * F::M0) & FM_;                                      \
       (col) += (uint64_t)(mk) * (md).p[0];                                         \
       MSM_CHECK_COL_ADD((unsigned __int128)(mk) * (md).p[0]);                      \
       MSM_CHECK_COL_END(col);                                                      \
-      MSM_CHECK(((uint32_t)(col) & LMASK) == 0);                                   \
-      (col) >>= LB;                                                                \
+      MSM_CHECK(((uint32_t)(col) & FM_) == 0);                                     \
+      (col) >>= F::B;                                                              \
     }                                                                              \
   } while (0)
 
 // r = a*b*R^-1 (mod p), class M.  Product scanning: column k gathers every a_i*b_j and m_i*p_j with
-// i+j = k in ONE 64-bit accumulator; m_k clears the low 28 bits and the column is shifted down.
-// Bound: limbs < 2^30  =>  14*(2^30)^2 + 14*(2^28)^2 + carry < 2^64.
+// i+j = k in ONE 64-bit accumulator; m_k clears the low B bits and the column is shifted down.  N limbs, NRED >= N reduction
+// steps (R = 2^(B*NRED)): columns 0 .. NRED-1 produce the m_k, columns NRED .. NRED+N-1 the result.
+// Bound (14 x 28): limbs < 2^30  =>  14*(2^30)^2 + 14*(2^28)^2 + carry < 2^64.
+// Bound (13 x 29): 13 * limb_a * limb_b + 13 * 2^58 + carry < 2^64, i.e. limb_a * limb_b < 3.9 * 2^58 -- the callers' business (te.hpp).
 template <class F>
 MSM_HD void fe_mul(Fe& r, const Fe& a, const Fe& b, const Modulus<F>& md) {
+  constexpr int N = F::N, NR = F::NRED, B = F::B;
+  constexpr uint32_t MASK = (1u << B) - 1;
+  static_assert(N <= NR && NR <= NL && N * B >= F::BITS, "limb shape");
   uint32_t m[NL], xs[NL], ys[NL];
   Fe t;
   uint64_t col = 0;
+  if (B == 28) {
 #pragma unroll
-  for (int i = 0; i < NL; i++) {
-    MSM_CHECK(a.v[i] < (1u << 30) && b.v[i] < (1u << 30));
+    for (int i = 0; i < N; i++) {
+      MSM_CHECK(a.v[i] < (1u << 30) && b.v[i] < (1u << 30));
+    }
   }
 #pragma unroll
-  for (int k = 0; k < NL; k++) {
+  for (int k = 0; k < NR; k++) {
     MSM_CHECK_COL_BEGIN();
+    const int lo = k > N - 1 ? k - (N - 1) : 0, hi = k < N - 1 ? k : N - 1;
+    int n = 0;
 #pragma unroll
-    for (int i = 0; i <= k; i++) {
-      xs[i] = a.v[i];
-      ys[i] = b.v[k - i];
+    for (int i = lo; i <= hi; i++) {
+      xs[n] = a.v[i];
+      ys[n] = b.v[k - i];
+      n++;
       MSM_CHECK_COL_ADD((unsigned __int128)a.v[i] * b.v[k - i]);
     }
-    mad_chain<false>(col, xs, ys, k + 1);
+    mad_chain<false>(col, xs, ys, n);
+    n = 0;
 #pragma unroll
-    for (int i = 0; i < k; i++) {
-      xs[i] = m[i];
-      ys[i] = md.p[k - i];
+    for (int i = lo; i < k; i++) {
+      xs[n] = m[i];
+      ys[n] = md.p[k - i];
+      n++;
       MSM_CHECK_COL_ADD((unsigned __int128)m[i] * md.p[k - i]);
     }
-    mad_chain<true>(col, xs, ys, k);
+    mad_chain<true>(col, xs, ys, n);
     MSM_MONT_STEP(F, col, m[k], md);
   }
 #pragma unroll
-  for (int k = NL; k < 2 * NL - 1; k++) {
+  for (int k = NR; k < NR + N - 1; k++) {
     MSM_CHECK_COL_BEGIN();
+    const int lo = k - (N - 1);
+    int n = 0;
 #pragma unroll
-    for (int i = k - NL + 1; i < NL; i++) {
-      xs[i - (k - NL + 1)] = a.v[i];
-      ys[i - (k - NL + 1)] = b.v[k - i];
+    for (int i = lo; i < N; i++) {
+      xs[n] = a.v[i];
+      ys[n] = b.v[k - i];
+      n++;
       MSM_CHECK_COL_ADD((unsigned __int128)a.v[i] * b.v[k - i]);
     }
-    mad_chain<false>(col, xs, ys, 2 * NL - 1 - k);
+    mad_chain<false>(col, xs, ys, n);
+    n = 0;
 #pragma unroll
-    for (int i = k - NL + 1; i < NL; i++) {
-      xs[i - (k - NL + 1)] = m[i];
-      ys[i - (k - NL + 1)] = md.p[k - i];
+    for (int i = lo; i < NR; i++) {
+      xs[n] = m[i];
+      ys[n] = md.p[k - i];
+      n++;
       MSM_CHECK_COL_ADD((unsigned __int128)m[i] * md.p[k - i]);
     }
-    mad_chain<true>(col, xs, ys, 2 * NL - 1 - k);
+    mad_chain<true>(col, xs, ys, n);
     MSM_CHECK_COL_END(col);
-    t.v[k - NL] = (uint32_t)col & LMASK;
-    col >>= LB;
+    t.v[k - NR] = (uint32_t)col & MASK;
+    col >>= B;
   }
-  MSM_CHECK(col < (1ull << 28));
-  t.v[NL - 1] = (uint32_t)col;
+  MSM_CHECK(col < (1ull << (B == 28 ? 28 : 30)));
+  t.v[N - 1] = (uint32_t)col;
+#pragma unroll
+  for (int i = N; i < NL; i++) t.v[i] = 0;
   r = t;
 }
 
@@ -251,6 +281,7 @@ MSM_HD void fe_mul(Fe& r, const Fe& a, const Fe& b, const Modulus<F>& md) {
 // values: a*b + c*d <= 2^10 p^2 as for fe_mul.
 template <class F>
 MSM_HD void fe_mul2(Fe& r, const Fe& a, const Fe& b, const Fe& c, const Fe& d, const Modulus<F>& md) {
+  static_assert(F::N == NL && F::NRED == NL && F::B == LB, "fe_mul2 is written for the 14 x 28 shape");
   uint32_t m[NL], xs[NL], ys[NL];
   Fe t;
   uint64_t col = 0;
@@ -325,6 +356,10 @@ MSM_HD void fe_mul2(Fe& r, const Fe& a, const Fe& b, const Fe& c, const Fe& d, c
 // Bound: limbs < 2^30  =>  7*2^30*2^31 + 2^60 + 14*(2^28)^2 + carry < 2^64.
 template <class F>
 MSM_HD void fe_sqr(Fe& r, const Fe& a, const Modulus<F>& md) {
+  if constexpr (F::N != NL) {   // 13 x 29: no dedicated squaring (the twisted-Edwards law has none on its hot path)
+    fe_mul<F>(r, a, a, md);
+    return;
+  } else {
   uint32_t m[NL], a2[NL], xs[NL], ys[NL];
   Fe t;
   uint64_t col = 0;
@@ -391,61 +426,78 @@ MSM_HD void fe_sqr(Fe& r, const Fe& a, const Modulus<F>& md) {
   }
   t.v[NL - 1] = (uint32_t)col;
   r = t;
+  }
 }
 
-// Limb-wise r = a + b.  Caller tracks bounds (limbs add, values add).
+// Limb-wise r = a + b.  Caller tracks bounds (limbs add, values add).  N = limbs in use (words N.. of the result are 0).
+template <int N = NL>
 MSM_HD void fe_add(Fe& r, const Fe& a, const Fe& b) {
 #pragma unroll
-  for (int i = 0; i < NL; i++) r.v[i] = a.v[i] + b.v[i];
+  for (int i = 0; i < N; i++) r.v[i] = a.v[i] + b.v[i];
+#pragma unroll
+  for (int i = N; i < NL; i++) r.v[i] = 0;
 }
 
+template <int N = NL>
 MSM_HD void fe_dbl(Fe& r, const Fe& a) {
 #pragma unroll
-  for (int i = 0; i < NL; i++) r.v[i] = a.v[i] << 1;
+  for (int i = 0; i < N; i++) r.v[i] = a.v[i] << 1;
+#pragma unroll
+  for (int i = N; i < NL; i++) r.v[i] = 0;
 }
 
 // Limb-wise r = a + (k*p lifted) - b.  `bias` is one of F::BIASk_l: k*p with each limb raised by
 // 2^l, so no limb underflows when b's limbs are <= 2^l and value(b) <= k*p.  value(r) = a + k*p - b.
+template <int N = NL>
 MSM_HD void fe_sub(Fe& r, const Fe& a, const Fe& b, const uint32_t (&bias)[NL]) {
 #pragma unroll
-  for (int i = 0; i < NL; i++) {
+  for (int i = 0; i < N; i++) {
     MSM_CHECK(bias[i] >= b.v[i]);
     MSM_CHECK((uint64_t)a.v[i] + bias[i] - b.v[i] < (1ull << 32));
     r.v[i] = a.v[i] + (bias[i] - b.v[i]);
   }
+#pragma unroll
+  for (int i = N; i < NL; i++) r.v[i] = 0;
 }
 
 // r = (k*p) - b  (negation, value in (0, k*p]).
+template <int N = NL>
 MSM_HD void fe_neg(Fe& r, const Fe& b, const uint32_t (&bias)[NL]) {
 #pragma unroll
-  for (int i = 0; i < NL; i++) {
+  for (int i = 0; i < N; i++) {
     MSM_CHECK(bias[i] >= b.v[i]);
     r.v[i] = bias[i] - b.v[i];
   }
+#pragma unroll
+  for (int i = N; i < NL; i++) r.v[i] = 0;
 }
 
-// One parallel carry pass: every limb keeps its low 28 bits and receives its lower neighbour's
-// overflow.  Limbs up to 2^32-1 come out < 2^28 + 16; the value is unchanged.
+// One parallel carry pass: every limb keeps its low B bits and receives its lower neighbour's
+// overflow.  Limbs up to 2^32-1 come out < 2^B + 2^(32-B); the top limb only receives; the value is unchanged.
+template <int N = NL, int B = LB>
 MSM_HD void fe_carry(Fe& r) {
-  uint32_t c[NL - 1];
+  constexpr uint32_t MASK = (1u << B) - 1;
+  uint32_t c[N - 1];
 #pragma unroll
-  for (int i = 0; i < NL - 1; i++) c[i] = r.v[i] >> LB;
-  r.v[0] &= LMASK;
+  for (int i = 0; i < N - 1; i++) c[i] = r.v[i] >> B;
+  r.v[0] &= MASK;
 #pragma unroll
-  for (int i = 1; i < NL - 1; i++) r.v[i] = (r.v[i] & LMASK) + c[i - 1];
-  r.v[NL - 1] += c[NL - 2];
+  for (int i = 1; i < N - 1; i++) r.v[i] = (r.v[i] & MASK) + c[i - 1];
+  r.v[N - 1] += c[N - 2];
 }
 
-// Sequential carry propagation to strictly normalized limbs (v[0..12] < 2^28).
+// Sequential carry propagation to strictly normalized limbs (v[0..N-2] < 2^B).
+template <int N = NL, int B = LB>
 MSM_HD void fe_normalize(Fe& r) {
+  constexpr uint32_t MASK = (1u << B) - 1;
   uint32_t c = 0;
 #pragma unroll
-  for (int i = 0; i < NL - 1; i++) {
+  for (int i = 0; i < N - 1; i++) {
     uint32_t t = r.v[i] + c;
-    r.v[i] = t & LMASK;
-    c = t >> LB;
+    r.v[i] = t & MASK;
+    c = t >> B;
   }
-  r.v[NL - 1] += c;
+  r.v[N - 1] += c;
 }
 
 // Cheap partial reduction for lazy values: in  value < 32p, limbs < 2^31;  out  value < 3p, strictly normalized.
@@ -453,6 +505,7 @@ MSM_HD void fe_normalize(Fe& r) {
 // one more unit of slack), so value - q*p stays non-negative and below 3p.  ~110 cheap ops, no multiplier chain.
 template <class F>
 MSM_HD void fe_weak_reduce(Fe& r) {
+  static_assert(F::N == NL && F::B == LB, "fe_weak_reduce is written for the 14 x 28 shape");
   fe_normalize(r);
   constexpr uint32_t PT = F::P[NL - 1];
   constexpr uint32_t MAGIC = (uint32_t)((1ull << 32) / (PT + 1));
@@ -473,39 +526,46 @@ MSM_HD void fe_weak_reduce(Fe& r) {
 }
 
 // a >= b on strictly normalized limbs.
+template <int N = NL>
 MSM_HD bool fe_geq(const Fe& a, const uint32_t (&b)[NL]) {
   bool ge = true;  // equal so far => a >= b
 #pragma unroll
-  for (int i = 0; i < NL; i++) {
+  for (int i = 0; i < N; i++) {
     if (a.v[i] != b[i]) ge = a.v[i] > b[i];
   }
   return ge;
 }
 
-// Canonical representative in [0, p), strictly normalized.  Input: limbs < 2^31, value < 64p.  Slow path
-// (zero tests in rare branches, final output); the hot loop never calls it.
+// Canonical representative in [0, p), strictly normalized.  Input: limbs < 2^31, value < 64p (and < 2^(B(N-1)+32): 9p for the
+// 13 x 29 shape).  Slow path (zero tests in rare branches, final output); the hot loop never calls it.
 template <class F>
 MSM_HD void fe_reduce(Fe& r) {
-  fe_normalize(r);
+  constexpr int N = F::N, B = F::B;
+  constexpr uint32_t MASK = (1u << B) - 1;
+  fe_normalize<N, B>(r);
 #pragma unroll 1
-  for (int k = 32; k >= 1; k >>= 1) {
+  for (int k = (N == NL ? 32 : 8); k >= 1; k >>= 1) {
     // subtract k*p if r >= k*p
     uint32_t kp[NL];
     uint64_t c = 0;
 #pragma unroll
     for (int i = 0; i < NL; i++) {
-      c += (uint64_t)F::P[i] * (uint32_t)k;
-      kp[i] = (i == NL - 1) ? (uint32_t)c : ((uint32_t)c & LMASK);
-      c >>= LB;
+      if (i < N) {
+        c += (uint64_t)F::P[i] * (uint32_t)k;
+        kp[i] = (i == N - 1) ? (uint32_t)c : ((uint32_t)c & MASK);
+        c >>= B;
+      } else {
+        kp[i] = 0;
+      }
     }
-    if (fe_geq(r, kp)) {
+    if (fe_geq<N>(r, kp)) {
       int32_t borrow = 0;
 #pragma unroll
-      for (int i = 0; i < NL; i++) {
+      for (int i = 0; i < N; i++) {
         int64_t d = (int64_t)r.v[i] - kp[i] + borrow;
-        if (i < NL - 1) {
-          r.v[i] = (uint32_t)d & LMASK;
-          borrow = (int32_t)(d >> LB);
+        if (i < N - 1) {
+          r.v[i] = (uint32_t)d & MASK;
+          borrow = (int32_t)(d >> B);
         } else {
           r.v[i] = (uint32_t)d;
         }
@@ -521,7 +581,7 @@ MSM_HD bool fe_is_zero_M(const Fe& a) {
   if (a.v[0] != 0 && a.v[0] != F::P[0]) return false;
   uint32_t z = 0, e = 0;
 #pragma unroll
-  for (int i = 0; i < NL; i++) {
+  for (int i = 0; i < F::N; i++) {
     z |= a.v[i];
     e |= a.v[i] ^ F::P[i];
   }
@@ -535,7 +595,7 @@ MSM_HD bool fe_is_zero_slow(const Fe& a) {
   fe_reduce<F>(t);
   uint32_t z = 0;
 #pragma unroll
-  for (int i = 0; i < NL; i++) z |= t.v[i];
+  for (int i = 0; i < F::N; i++) z |= t.v[i];
   return z == 0;
 }
 
@@ -569,37 +629,48 @@ MSM_HD uint32_t sel_u32(uint32_t if_clear, uint32_t if_set, const LaneMask& k) {
 #endif
 }
 
+template <int N = NL>
 MSM_HD void fe_cmov(Fe& r, const Fe& a, const LaneMask& k) {
 #pragma unroll
-  for (int i = 0; i < NL; i++) r.v[i] = sel_u32(r.v[i], a.v[i], k);
+  for (int i = 0; i < N; i++) r.v[i] = sel_u32(r.v[i], a.v[i], k);
 }
-MSM_HD void fe_cmov(Fe& r, const Fe& a, bool take) { fe_cmov(r, a, lane_mask(take)); }
+template <int N = NL>
+MSM_HD void fe_cmov(Fe& r, const Fe& a, bool take) { fe_cmov<N>(r, a, lane_mask(take)); }
 
 // ---- ABI conversions (6 x u64 little-endian, Montgomery radix 2^384  <->  internal) ----------
 
-// 48 bytes (12 u32 words, little-endian) -> radix-2^28 limbs of the same integer.
+// 48 bytes (12 u32 words, little-endian) -> radix-2^B limbs of the same integer (the top limb takes what is left: for 13 x 29 the
+// value must stay below 2^380).
+template <int N = NL, int B = LB>
 MSM_HD void fe_from_words(Fe& r, const uint32_t* w) {
+  constexpr uint32_t MASK = (1u << B) - 1;
 #pragma unroll
   for (int i = 0; i < NL; i++) {
-    int bit = LB * i;
+    if (i >= N) {
+      r.v[i] = 0;
+      continue;
+    }
+    int bit = B * i;
     int wi = bit >> 5, sh = bit & 31;
     uint64_t lo = (wi < 12) ? w[wi] : 0;
     uint64_t hi = (wi + 1 < 12) ? w[wi + 1] : 0;
-    r.v[i] = (uint32_t)(((lo | (hi << 32)) >> sh)) & LMASK;
+    const uint32_t x = (uint32_t)(((lo | (hi << 32)) >> sh));
+    r.v[i] = (i == N - 1 && N * B < 384) ? x : (x & MASK);
   }
 }
 
 // strictly normalized limbs with value < 2^384 -> 12 u32 words.
+template <int N = NL, int B = LB>
 MSM_HD void fe_to_words(uint32_t* w, const Fe& a) {
 #pragma unroll
   for (int j = 0; j < 12; j++) {
     int bit = 32 * j;
-    int li = bit / LB, sh = bit % LB;
-    uint64_t acc = (uint64_t)a.v[li] >> sh;
-    int have = LB - sh;
-    if (li + 1 < NL) acc |= (uint64_t)a.v[li + 1] << have;
-    have += LB;
-    if (have < 32 && li + 2 < NL) acc |= (uint64_t)a.v[li + 2] << have;
+    int li = bit / B, sh = bit % B;
+    uint64_t acc = li < N ? (uint64_t)a.v[li] >> sh : 0;
+    int have = B - sh;
+    if (li + 1 < N) acc |= (uint64_t)a.v[li + 1] << have;
+    have += B;
+    if (have < 32 && li + 2 < N) acc |= (uint64_t)a.v[li + 2] << have;
     w[j] = (uint32_t)acc;
   }
 }
@@ -607,6 +678,7 @@ MSM_HD void fe_to_words(uint32_t* w, const Fe& a) {
 // ABI Montgomery (x*2^384 mod p, canonical) -> internal class M (x*2^392 mod p).
 template <class F>
 MSM_HD void fe_from_abi(Fe& r, const uint32_t* w, const Modulus<F>& md) {
+  static_assert(F::N == NL && F::B == LB, "the ABI boundary is crossed in the 14 x 28 shape");
   Fe t, c;
   fe_from_words(t, w);
   fe_set(c, F::CIN);
@@ -621,6 +693,27 @@ MSM_HD void fe_to_abi(uint32_t* w, const Fe& a, const Modulus<F>& md) {
   fe_mul<F>(t, a, c, md);
   fe_reduce<F>(t);
   fe_to_words(w, t);
+}
+
+// ---- between the two shapes of BLS12-377 Fq (same residue, Montgomery radix 2^392 <-> 2^406) ---------------------------------
+// in: canonical (fe_reduce'd) 14 x 28 value x*2^392;  out: class M 13 x 29 value x*2^406
+MSM_HD void fe_28_to_29(Fe& r, const Fe& a, const Modulus<Bls12_377_Fq29>& md29) {
+  uint32_t w[12];
+  fe_to_words(w, a);
+  Fe t, c;
+  fe_from_words<Bls12_377_Fq29::N, Bls12_377_Fq29::B>(t, w);
+  fe_set(c, Bls12_377_Fq29::FROM28);
+  fe_mul<Bls12_377_Fq29>(r, t, c, md29);
+}
+// in: any bounded 13 x 29 value (< 9p) x*2^406;  out: class M 14 x 28 value x*2^392
+MSM_HD void fe_29_to_28(Fe& r, const Fe& a, const Modulus<Bls12_377_Fq>& md28) {
+  Fe t = a, c;
+  fe_reduce<Bls12_377_Fq29>(t);
+  uint32_t w[12];
+  fe_to_words<Bls12_377_Fq29::N, Bls12_377_Fq29::B>(w, t);
+  fe_from_words(t, w);
+  fe_set(c, Bls12_377_Cross::TO28);
+  fe_mul<Bls12_377_Fq>(r, t, c, md28);
 }
 
 }  // namespace msm

@@ -83,6 +83,7 @@ struct Fp64 {
   bool adx = false;  // mulx / adcx / adox present: mul() takes the assembly path
   F64 one;           // R mod p
   F64 from28;        // 2^376 mod p: mont_mul(v, from28) turns v = x * 2^392 (device radix) into x * 2^384
+  F64 from29;        // 2^362 mod p: the same for the 13 x 29 shape of BLS12-377 (v = x * 2^406; fp28.hpp)
   F64 two_d;         // twisted-Edwards 2d (BLS12-377 only), Montgomery form
   F64 sqrt3, fsc_sqrt3;   // constants of the map back to short Weierstrass (te.hpp::te_to_sw)
 
@@ -190,16 +191,16 @@ struct Fp64 {
 
   const F64& one_el() const { return one; }
   void store(uint8_t* out, const F64& a) const { memcpy(out, a.l, 48); }
-  // device field element (any bounded lazy value) -> F64
+  // device field element (any bounded lazy value, in the limb shape of F) -> F64
   template <class F>
   void from_device(F64& r, const Fe& a) const {
     Fe t = a;
     fe_reduce<F>(t);
     uint32_t w[12];
-    fe_to_words(w, t);
+    fe_to_words<F::N, F::B>(w, t);
     F64 v;
     for (int i = 0; i < 6; i++) v.l[i] = (uint64_t)w[2 * i] | ((uint64_t)w[2 * i + 1] << 32);
-    mul(r, v, from28);
+    mul(r, v, F::B == 29 ? from29 : from28);
   }
   void from_limbs28(F64& r, const uint32_t (&c)[NL]) const {   // a plain integer given as radix-2^28 limbs (< p)
     Fe t;
@@ -223,9 +224,10 @@ struct Fp64 {
     // 2^k mod p by repeated doubling of 1
     F64 v{};
     v.l[0] = 1;
-    F64 p376{}, p384{}, p768{};
+    F64 p362{}, p376{}, p384{}, p768{};
     for (int k = 1; k <= 768; k++) {
       add(v, v, v);
+      if (k == 362) p362 = v;
       if (k == 376) p376 = v;
       if (k == 384) p384 = v;
       if (k == 768) p768 = v;
@@ -233,6 +235,8 @@ struct Fp64 {
     one = p384;
     // from28 must be the Montgomery image of 2^-8, i.e. 2^-8 * 2^384 = 2^376
     from28 = p376;
+    // ... and of 2^-22 for values in Montgomery radix 2^406
+    from29 = p362;
     (void)p768;
   }
   // Montgomery image of a constant stored in the device representation (x * 2^392 mod p as radix-2^28 limbs)
@@ -475,7 +479,8 @@ inline bool te64_dbl(const Fp64& f, Xyzz64& a) {
 
 // Horner on the Edwards image, then back to short Weierstrass (te.hpp::te_to_sw), as an XYZZ64 affine point.
 // false: a vanishing denominator was hit (possible only off the odd-order subgroup) -- the caller repeats on XYZZ.
-template <class F>
+// FD = the field constants whose limb shape the device sums are in (Bls12_377_Fq29 when the Edwards kernels run on 13 x 29 limbs).
+template <class F, class FD = F>
 inline bool fold_windows_te64(const Fp64& f, Xyzz64& out, const Xyzz* sums, int windows, int c) {
   Xyzz64 acc{};
   acc.y = f.one;
@@ -485,7 +490,7 @@ inline bool fold_windows_te64(const Fp64& f, Xyzz64& out, const Xyzz* sums, int 
       for (int i = 0; i < c; i++)
         if (!te64_dbl(f, acc)) return false;
     Xyzz64 s;
-    xyzz64_from_device<F>(f, s, sums[w]);
+    xyzz64_from_device<FD>(f, s, sums[w]);
     if (f.is_zero(s.zz)) return false;
     if (!te64_add(f, acc, s)) return false;
   }

@@ -202,7 +202,8 @@ static void t_normalize(const uint8_t* in, uint8_t* out) {
 }
 
 // ---- twisted-Edwards image of BLS12-377 G1 (te.hpp) ------------------------------------------------------------
-using TF = Bls12_377_Fq;
+using TF = Bls12_377_Fq;   // the shape the birational map runs in (14 x 28)
+using TEF = TeFq;          // the shape the law runs in (13 x 29 unless built with -DMSM_TE_LIMBS29=0): te.hpp
 
 // arkworks Affine image -> TE base record; false when the point has no image (or is flagged infinite).
 static bool te_map_host(TeAffine& out, const uint8_t* img, const Modulus<TF>& md) {
@@ -219,9 +220,10 @@ static bool te_map_host(TeAffine& out, const uint8_t* img, const Modulus<TF>& md
   return true;
 }
 
-static int te_finish_host(uint8_t* out, const Xyzz& acc, const Modulus<TF>& md) {
-  if (te_failed<TF>(acc)) return 2;
-  Xyzz sw;
+static int te_finish_host(uint8_t* out, const Xyzz& acc_te, const Modulus<TF>& md) {
+  if (te_failed<TEF>(acc_te)) return 2;
+  Xyzz sw, acc;
+  te_point_to_28<TEF>(acc, acc_te, md);
   te_to_sw<TF>(sw, acc, md);
   xyzz_to_projective_abi<FpEl<TF>>(out, sw, md);
   return 0;
@@ -275,36 +277,82 @@ int ht_te_map(const uint8_t* img, uint8_t* out) {
 // 1 = a point without image, 2 = an addition hit a vanishing denominator (Z = 0).
 int ht_te_madd_chain(const uint8_t* pts, size_t stride, const uint8_t* neg, size_t n, uint8_t* out) {
   Modulus<TF> md;
+  Modulus<TEF> tmd;
   Xyzz acc;
-  te_set_identity<TF>(acc);
+  te_set_identity<TEF>(acc);
   for (size_t i = 0; i < n; i++) {
     if (pts[i * stride + 96]) continue;
-    TeAffine t;
-    if (!te_map_host(t, pts + i * stride, md)) return 1;
-    te_madd<TF>(acc, t, neg[i] != 0, md);
-    if (te_failed<TF>(acc)) return 2;
+    TeAffine t28, t;
+    if (!te_map_host(t28, pts + i * stride, md)) return 1;
+    te_record_to<TEF>(t, t28, tmd);
+    te_madd<TEF>(acc, t, neg[i] != 0, tmd);
+    if (te_failed<TEF>(acc)) return 2;
   }
   return te_finish_host(out, acc, md);
 }
 // (chain over the first na points) + (chain over the rest) through the unified extended addition, then `dbl` doublings.
 int ht_te_add_chains(const uint8_t* pts, size_t stride, size_t na, size_t nb, int dbl, uint8_t* out) {
   Modulus<TF> md;
+  Modulus<TEF> tmd;
   Xyzz a, b;
-  te_set_identity<TF>(a);
-  te_set_identity<TF>(b);
+  te_set_identity<TEF>(a);
+  te_set_identity<TEF>(b);
   for (size_t i = 0; i < na + nb; i++) {
     if (pts[i * stride + 96]) continue;
-    TeAffine t;
-    if (!te_map_host(t, pts + i * stride, md)) return 1;
-    te_madd<TF>(i < na ? a : b, t, false, md);
+    TeAffine t28, t;
+    if (!te_map_host(t28, pts + i * stride, md)) return 1;
+    te_record_to<TEF>(t, t28, tmd);
+    te_madd<TEF>(i < na ? a : b, t, false, tmd);
   }
-  te_add<TF>(a, b, md);
-  if (te_failed<TF>(a)) return 2;
+  te_add<TEF>(a, b, tmd);
+  if (te_failed<TEF>(a)) return 2;
   for (int i = 0; i < dbl; i++) {
-    te_dbl<TF>(a, md);
-    if (te_failed<TF>(a)) return 2;
+    te_dbl<TEF>(a, tmd);
+    if (te_failed<TEF>(a)) return 2;
   }
   return te_finish_host(out, a, md);
+}
+// The 13 x 29 shape of BLS12-377 Fq on its own: out = a * b (ABI Montgomery images in and out), the product formed by
+// fe_mul<Bls12_377_Fq29> between the two re-radixing steps (fe_28_to_29 / fe_29_to_28).
+int ht_fe29_mul(const uint8_t* a, const uint8_t* b, uint8_t* out) {
+  Modulus<TF> md;
+  Modulus<Bls12_377_Fq29> md29;
+  Fe x, y, x29, y29, z29, z;
+  fe_from_abi<TF>(x, (const uint32_t*)a, md);
+  fe_from_abi<TF>(y, (const uint32_t*)b, md);
+  fe_reduce<TF>(x);
+  fe_reduce<TF>(y);
+  fe_28_to_29(x29, x, md29);
+  fe_28_to_29(y29, y, md29);
+  fe_mul<Bls12_377_Fq29>(z29, x29, y29, md29);
+  fe_29_to_28(z, z29, md);
+  uint32_t w[12];
+  fe_to_abi<TF>(w, z, md);
+  memcpy(out, w, 48);
+  return 0;
+}
+// Worst-case limbs through the 13 x 29 Edwards law: every coordinate / record field is forced to the LARGEST limbs its class
+// allows (class M: 2^29 - 1 everywhere and the top limb of 1.5p; records: canonical, i.e. the limbs of p - 1 raised to 2^29 - 1 below
+// the top), `rounds` mixed additions and one full addition are run, and the MSM_CHECK column sums decide.  Values are meaningless.
+int ht_te29_extreme(int rounds) {
+  using F = Bls12_377_Fq29;
+  Modulus<F> md;
+  Fe big;
+  for (int i = 0; i < F::N - 1; i++) big.v[i] = (1u << 29) - 1;
+  big.v[F::N - 1] = F::P[F::N - 1] + (F::P[F::N - 1] >> 1) + 1;   // the top limb of 1.5p
+  for (int i = F::N; i < NL; i++) big.v[i] = 0;
+  Fe rec = big;
+  rec.v[F::N - 1] = F::P[F::N - 1];
+  Xyzz acc{big, big, big, big}, other{big, big, big, big};
+  TeAffine b{rec, rec, rec};
+  for (int r = 0; r < rounds; r++) {
+    Xyzz t = acc;
+    te_madd<F>(t, b, (r & 1) != 0, md);
+    t = acc;
+    te_madd<F, true>(t, b, (r & 1) != 0, md);
+  }
+  te_add<F>(acc, other, md);
+  return 0;
 }
 }
 
@@ -484,9 +532,34 @@ static int t_devop(int op, const uint32_t* in, int iw, uint32_t* out, int ow, si
   return 0;
 }
 
+// the op subset of the 13 x 29 shape (devtest_ops.hpp: DT_CURVE_TE29)
+static int t_devop_te29(int op, const uint32_t* in, int iw, uint32_t* out, int ow, size_t n) {
+  using C = Bls12_377_G1_29;
+  for (size_t i = 0; i < n; i++) {
+    const uint32_t* a = in + i * iw;
+    uint32_t* r = out + i * ow;
+    switch (op) {
+#define DT_CASE(OP) case OP: devtest_apply<C, OP>(a, r); break;
+      DT_CASE(DT_FE_MUL)
+      DT_CASE(DT_TE_MADD)
+      DT_CASE(DT_TE_MADD_SWAPPED)
+      DT_CASE(DT_TE_ADD)
+      DT_CASE(DT_TE_DBL)
+#undef DT_CASE
+      default: return -1;
+    }
+  }
+  return 0;
+}
+
 extern "C" int ht_devop(int curve, int op, const uint32_t* in, uint32_t* out, size_t n) {
   int iw = 0, ow = 0;
-  if (curve < 0 || curve > 3 || !in || !out) return -1;
+  if (curve < 0 || curve > DT_CURVE_TE29 || !in || !out) return -1;
+  if (curve == DT_CURVE_TE29) {
+    if (!dt_op_in_te29(op)) return -1;
+    devtest_shape(op, NL, iw, ow);
+    return iw ? t_devop_te29(op, in, iw, out, ow, n) : -1;
+  }
   devtest_shape(op, curve >= 2 ? 2 * NL : NL, iw, ow);
   if (!iw) return -1;
   switch (curve) {
@@ -498,7 +571,12 @@ extern "C" int ht_devop(int curve, int op, const uint32_t* in, uint32_t* out, si
 }
 
 extern "C" int ht_devop_shape(int curve, int op, int* in_words, int* out_words) {
-  if (!in_words || !out_words || curve < 0 || curve > 3) return -1;
+  if (!in_words || !out_words || curve < 0 || curve > DT_CURVE_TE29) return -1;
+  if (curve == DT_CURVE_TE29) {
+    *in_words = *out_words = 0;
+    if (dt_op_in_te29(op)) devtest_shape(op, NL, *in_words, *out_words);
+    return (*in_words) ? 0 : -1;
+  }
   devtest_shape(op, curve >= 2 ? 2 * NL : NL, *in_words, *out_words);
   if (curve != 0 && ((op >= DT_TE_MADD && op <= DT_TE_DBL) || op == DT_TE_ADD_QUAD)) *in_words = *out_words = 0;
   return (*in_words) ? 0 : -1;

@@ -6,13 +6,13 @@
 namespace msm {
 
 namespace {
-using G = TeLaw<Bls12_377_Fq>;
+using G = TeLaw<TeFq>;   // the limb shape of the Edwards path: te.hpp
 inline uint32_t te_blocks(uint64_t n) { return (uint32_t)((n + 255) / 256); }
 }  // namespace
 
 hipError_t LaunchTe::convert(const AffineDev* in, const uint8_t* inf, uint32_t n, uint32_t J, Fe* prefix, TeAffineDev* out, uint32_t* flags,
                              hipStream_t st) {
-  hipLaunchKernelGGL((k_te_convert<Bls12_377_Fq>), dim3(te_blocks(((uint64_t)n + J - 1) / J)), dim3(256), 0, st, in, inf, n, J, prefix, out, flags);
+  hipLaunchKernelGGL((k_te_convert<Bls12_377_Fq, TeFq>), dim3(te_blocks(((uint64_t)n + J - 1) / J)), dim3(256), 0, st, in, inf, n, J, prefix, out, flags);
   return hipGetLastError();
 }
 
@@ -25,7 +25,7 @@ hipError_t LaunchTe::accumulate(const uint2* entries, const uint32_t* n_real, ui
 hipError_t LaunchTe::segreduce(const XyzzDev* in_slots, const uint32_t* in_keys, uint32_t n_in, uint32_t K, SegOut out, uint32_t nlanes,
                                uint32_t quad_limit, uint32_t* flags, hipStream_t st) {
   if (nlanes <= quad_limit)
-    hipLaunchKernelGGL((k_segreduce_quad<TeQuad<Bls12_377_Fq>>), dim3(te_blocks(4ull * nlanes)), dim3(256), 0, st, in_slots, in_keys, n_in, K, out, nlanes, flags);
+    hipLaunchKernelGGL((k_segreduce_quad<TeQuad<TeFq>>), dim3(te_blocks(4ull * nlanes)), dim3(256), 0, st, in_slots, in_keys, n_in, K, out, nlanes, flags);
   else
     hipLaunchKernelGGL((k_segreduce<G>), dim3(te_blocks(nlanes)), dim3(256), 0, st, in_slots, in_keys, n_in, K, out, nlanes, flags);
   return hipGetLastError();
@@ -45,7 +45,7 @@ hipError_t LaunchTe::reduce_scan_step(const XyzzDev* in, const XyzzDev* in2, Xyz
                                       uint32_t quad_limit, uint32_t* flags, hipStream_t st) {
   const uint64_t threads = (uint64_t)windows * (mode == 1 ? d : nb);
   if (threads <= quad_limit)
-    hipLaunchKernelGGL((k_reduce_scan_step_quad<TeQuad<Bls12_377_Fq>>), dim3(te_blocks(4 * threads)), dim3(256), 0, st, in, in2, out, nb, windows, d, mode, flags);
+    hipLaunchKernelGGL((k_reduce_scan_step_quad<TeQuad<TeFq>>), dim3(te_blocks(4 * threads)), dim3(256), 0, st, in, in2, out, nb, windows, d, mode, flags);
   else
     hipLaunchKernelGGL((k_reduce_scan_step<G>), dim3(te_blocks(threads)), dim3(256), 0, st, in, in2, out, nb, windows, d, mode, flags);
   return hipGetLastError();

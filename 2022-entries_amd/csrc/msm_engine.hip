@@ -889,7 +889,13 @@ struct HostTail<FpEl<F>> {
   static void set_inf(Pt& a) { sw64_set_inf(a); }
   static void add(Pt& a, const Pt& b) { sw64_add(fp64_of<F>(), a, b); }
   static void fold(Pt& out, const Xyzz* sums, int windows, int c) { fold_windows64<F>(fp64_of<F>(), out, sums, windows, c); }
-  static bool fold_te(Pt& out, const Xyzz* sums, int windows, int c) { return fold_windows_te64<F>(fp64_of<F>(), out, sums, windows, c); }
+  // (the Edwards kernels hold their points in the limb shape of TeFq: te.hpp)
+  static bool fold_te(Pt& out, const Xyzz* sums, int windows, int c) {
+    if constexpr (std::is_same_v<F, Bls12_377_Fq>)
+      return fold_windows_te64<F, TeFq>(fp64_of<F>(), out, sums, windows, c);
+    else
+      return fold_windows_te64<F>(fp64_of<F>(), out, sums, windows, c);
+  }
   static void to_abi(uint8_t* out, const Pt& a) { sw64_to_abi(fp64_of<F>(), out, a); }
 };
 

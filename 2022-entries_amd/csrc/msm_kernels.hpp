@@ -745,7 +745,9 @@ __global__ void __launch_bounds__(256) k_pre_normalize(const XyzzDevT<typename E
 // lane: the forward pass stores the running products of the map's denominators, the backward pass peels one inverse per
 // point.  Points without an image are counted in flags[0] (the engine then keeps the base set on the XYZZ path) and get a
 // harmless filler; bases flagged infinite are never gathered.
-template <class F>
+// The map runs in the 14 x 28 shape of F (init-time work); the records are written in the limb shape of TF, the field the
+// Edwards kernels compute in (te_record_to).
+template <class F, class TF>
 __global__ void __launch_bounds__(256) k_te_convert(const AffineDev* __restrict__ in, const uint8_t* __restrict__ inf, uint32_t n, uint32_t J,
                                                     Fe* __restrict__ prefix, TeAffineDev* __restrict__ out, uint32_t* __restrict__ flags) {
   const uint32_t t = blockIdx.x * 256 + threadIdx.x;
@@ -753,6 +755,7 @@ __global__ void __launch_bounds__(256) k_te_convert(const AffineDev* __restrict_
   if (lo >= n) return;
   const uint64_t hi = (lo + J < n) ? lo + J : n;
   Modulus<F> md;
+  Modulus<TF> tmd;
   Fe run;
   fe_set(run, F::ONE);
   uint32_t bad = 0;
@@ -771,8 +774,8 @@ __global__ void __launch_bounds__(256) k_te_convert(const AffineDev* __restrict_
   fe_inv<F>(inv, run, md);
   for (uint64_t j = hi; j-- > lo;) {
     TeAffine o;
-    fe_set(o.ymx, F::ONE);   // the identity (0, 1): a harmless filler
-    fe_set(o.ypx, F::ONE);
+    fe_set(o.ymx, TF::ONE);   // the identity (0, 1): a harmless filler
+    fe_set(o.ypx, TF::ONE);
     fe_zero(o.td);
     if (!inf[j]) {
       const AffineDev a = in[j];
@@ -783,7 +786,9 @@ __global__ void __launch_bounds__(256) k_te_convert(const AffineDev* __restrict_
         const Fe pre = prefix[j];
         fe_mul<F>(ti, inv, pre, md);      // 1 / den_j
         fe_mul<F>(inv, inv, den, md);
-        te_map_finish<F>(o, u, v, w, ti, md);
+        TeAffine o28;
+        te_map_finish<F>(o28, u, v, w, ti, md);
+        te_record_to<TF>(o, o28, tmd);
       }
     }
     TeAffineDev od;

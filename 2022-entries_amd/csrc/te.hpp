@@ -15,6 +15,11 @@
 //     r-torsion).  Off the subgroup an addition can hit a vanishing denominator, which shows as Z3 = 0: every kernel
 //     checks it after each addition and raises a flag, and the engine then repeats the run on the XYZZ path.
 //
+// Two limb shapes (fp28.hpp): the law below is written once over the field constants F and runs either on Bls12_377_Fq (14 x 28,
+// R = 2^392) or on Bls12_377_Fq29 (13 x 29, R = 2^406: 337 instead of 378 multiply-adds per product).  The 29-bit shape has one bit
+// less lazy headroom, which costs two carry passes in te_tail (and two more in the full addition); the birational map itself --
+// init-time work -- always runs in the 14 x 28 shape and k_te_convert re-radixes its records (te_record_to_29).
+//
 // Extended points reuse XyzzT<Fe>: x = X, y = Y, zz = Z, zzz = T with X Y = Z T; all four are class M (strictly normalized
 // limbs, value < 1.5p).  Base records hold (Y - X, Y + X, 2 d X Y), canonical: what the mixed addition multiplies by, so the
 // hot loop neither forms them (42 limb operations per addition) nor selects between them for a negated base -- -(X, Y) =
@@ -23,6 +28,27 @@
 #include "curve.hpp"
 
 namespace msm {
+
+#ifndef MSM_TE_LIMBS29
+#define MSM_TE_LIMBS29 1   // 0 = the twisted-Edwards path on 14 x 28 limbs as in rounds 2-5 (A/B: profiles/r06_ab_limbs29.txt)
+#endif
+#if MSM_TE_LIMBS29
+using TeFq = Bls12_377_Fq29;
+#else
+using TeFq = Bls12_377_Fq;
+#endif
+
+// the Edwards constant 2d in the representation of F
+template <class F>
+struct TeConst;
+template <>
+struct TeConst<Bls12_377_Fq> {
+  static MSM_HD void k2d(Fe& r) { fe_set(r, Bls12_377_Te::K2D); }
+};
+template <>
+struct TeConst<Bls12_377_Fq29> {
+  static MSM_HD void k2d(Fe& r) { fe_set(r, Bls12_377_Cross::K2D29); }
+};
 
 struct TeAffine {
   Fe ymx, ypx, td;   // Y - X, Y + X, 2 d X Y
@@ -70,15 +96,23 @@ MSM_HD bool te_failed(const Xyzz& a) {
   return fe_is_zero_M<F>(a.zz);
 }
 
-// Shared tail: from A, B, C (class M) and D (limbs < 2^29, value < 3p) produce the sum.
+// Shared tail: from A, B, C (class M) and D (limbs < 2^(B+1), value < 3p) produce the sum.
 //   E = B - A, F = D - C, G = D + C, H = B + A;  X3 = E F, Y3 = G H, T3 = E H, Z3 = F G.
+// Limb bounds in units of 2^B (class M = 1):  E < 3, F < 4, G < 3, H < 2.  14 x 28 multiplies limbs < 4 x 4; 13 x 29 needs
+// limb_a * limb_b < 3.9, so F and H are carried first (-> 1 + eps): E F' , G H', E H' < 3 and F' G < 3.  The top limbs are not
+// shortened by a carry pass (F: 4p >> 348 = 3.4 * 2^29) and enter two terms of a column; tools/limb_bounds29.py has the exact sums.
 template <class F>
 MSM_HD void te_tail(Xyzz& r, const Fe& A, const Fe& B, const Fe& C, const Fe& D, const Modulus<F>& md) {
+  constexpr int N = F::N;
   Fe e, f, g, h;
-  fe_sub(e, B, A, F::BIAS2_28);   // (0.5p, 3.5p), limbs < 2^28 + 2^29
-  fe_sub(f, D, C, F::BIAS2_28);   // (0.5p, 5p),   limbs < 2^29 + 2^29
-  fe_add(g, D, C);                // < 4.5p,       limbs < 2^29 + 2^28
-  fe_add(h, B, A);                // < 3p,         limbs < 2^29
+  fe_sub<N>(e, B, A, F::BIAS2_L);   // (0.5p, 3.5p), limbs < 2^B + 2^(B+1)
+  fe_sub<N>(f, D, C, F::BIAS2_L);   // (0.5p, 5p),   limbs < 2^(B+1) + 2^(B+1)
+  fe_add<N>(g, D, C);                // < 4.5p,       limbs < 2^(B+1) + 2^B
+  fe_add<N>(h, B, A);                // < 3p,         limbs < 2^(B+1)
+  if constexpr (F::B == 29) {
+    fe_carry<N, F::B>(f);
+    fe_carry<N, F::B>(h);
+  }
   fe_mul<F>(r.x, e, f, md);       // 3.5p * 5p
   fe_mul<F>(r.y, g, h, md);
   fe_mul<F>(r.zzz, e, h, md);
@@ -90,40 +124,46 @@ MSM_HD void te_tail(Xyzz& r, const Fe& A, const Fe& B, const Fe& C, const Fe& D,
 // addresses); only the sign of 2dXY is left to apply.
 template <class F, bool SWAPPED = false>
 MSM_HD void te_madd(Xyzz& acc, const TeAffine& b, bool negate, const Modulus<F>& md) {
+  constexpr int N = F::N;
   const LaneMask neg = lane_mask(negate);
   Fe ymx = b.ymx, ypx = b.ypx, td, ntd;
   if (!SWAPPED) {
-    fe_cmov(ymx, b.ypx, neg);
-    fe_cmov(ypx, b.ymx, neg);
+    fe_cmov<N>(ymx, b.ypx, neg);
+    fe_cmov<N>(ypx, b.ymx, neg);
   }
-  fe_neg(ntd, b.td, F::BIAS2_28);       // (p, 2p], limbs < 2^29
+  fe_neg<N>(ntd, b.td, F::BIAS2_L);       // (p, 2p], limbs < 2^(B+1)
   td = b.td;
-  fe_cmov(td, ntd, neg);
+  fe_cmov<N>(td, ntd, neg);
   Fe a1, b1, A, B, C, D;
-  fe_sub(a1, acc.y, acc.x, F::BIAS2_28);   // (0, 4p), limbs < 2^28 + 2^29
-  fe_add(b1, acc.y, acc.x);                // < 4p,    limbs < 2^29
-  fe_mul<F>(A, a1, ymx, md);               // 4p * p
-  fe_mul<F>(B, b1, ypx, md);
-  fe_mul<F>(C, acc.zzz, td, md);
-  fe_dbl(D, acc.zz);                       // < 3p, limbs < 2^29
+  fe_sub<N>(a1, acc.y, acc.x, F::BIAS2_L);   // (0, 4p), limbs < 2^B + 2^(B+1)
+  fe_add<N>(b1, acc.y, acc.x);                // < 4p,    limbs < 2^(B+1)
+  fe_mul<F>(A, a1, ymx, md);               // 4p * p     (13 x 29: limbs 3 x 1)
+  fe_mul<F>(B, b1, ypx, md);               //            (2 x 1)
+  fe_mul<F>(C, acc.zzz, td, md);           //            (1 x 2)
+  fe_dbl<N>(D, acc.zz);                       // < 3p, limbs < 2^(B+1)
   te_tail<F>(acc, A, B, C, D, md);
 }
 
 // acc += b, both extended (9M: add-2008-hwcd-3 with k = 2d).  Unified: b may equal acc.
 template <class F>
 MSM_HD void te_add(Xyzz& acc, const Xyzz& b, const Modulus<F>& md) {
+  constexpr int N = F::N;
   Fe a1, a2, b1, b2, A, B, C, D, kt, zz, k;
-  fe_sub(a1, acc.y, acc.x, F::BIAS2_28);   // (0, 4p)
-  fe_sub(a2, b.y, b.x, F::BIAS2_28);
-  fe_add(b1, acc.y, acc.x);                // < 4p
-  fe_add(b2, b.y, b.x);
-  fe_set(k, Bls12_377_Te::K2D);
+  fe_sub<N>(a1, acc.y, acc.x, F::BIAS2_L);   // (0, 4p)
+  fe_sub<N>(a2, b.y, b.x, F::BIAS2_L);
+  fe_add<N>(b1, acc.y, acc.x);                // < 4p
+  fe_add<N>(b2, b.y, b.x);
+  if constexpr (F::B == 29) {   // limbs 3 x 3 and 2 x 2 would overflow a column of 13: one operand of each product is carried
+    fe_carry<N, F::B>(a1);
+    fe_carry<N, F::B>(b1);
+  }
+  TeConst<F>::k2d(k);
   fe_mul<F>(kt, b.zzz, k, md);
   fe_mul<F>(zz, acc.zz, b.zz, md);
   fe_mul<F>(A, a1, a2, md);                // 4p * 4p
   fe_mul<F>(B, b1, b2, md);
   fe_mul<F>(C, acc.zzz, kt, md);
-  fe_dbl(D, zz);
+  fe_dbl<N>(D, zz);
   te_tail<F>(acc, A, B, C, D, md);
 }
 
@@ -140,42 +180,48 @@ MSM_HD void te_add(Xyzz& acc, const Xyzz& b, const Modulus<F>& md) {
 // a + b; all four lanes of the quad must call it together.
 template <class F>
 __device__ __forceinline__ void te_add_quad(Fe& a, const Fe& b, uint32_t q, const Modulus<F>& md) {
+  constexpr int N = F::N;
   Fe pa, pb, u, v, t0, t1;
-  fe_quad_perm<0xB1>(pa, a);                  // lanes 0 <-> 1, 2 <-> 3
-  fe_quad_perm<0xB1>(pb, b);
+  fe_quad_perm<0xB1, N>(pa, a);                  // lanes 0 <-> 1, 2 <-> 3
+  fe_quad_perm<0xB1, N>(pb, b);
   // lane 0 (own X, partner Y): Y - X;  lane 1 (own Y, partner X): Y + X
-  fe_sub(t0, pa, a, F::BIAS2_28);             // (0, 4p), limbs < 2^28 + 2^29
-  fe_add(t1, a, pa);                          // < 4p, limbs < 2^29
-  fe_select(u, t1, t0, q == 0);
-  fe_sub(t0, pb, b, F::BIAS2_28);
-  fe_add(t1, b, pb);
-  fe_select(v, t1, t0, q == 0);
+  fe_sub<N>(t0, pa, a, F::BIAS2_L);             // (0, 4p), limbs < 2^B + 2^(B+1)
+  fe_add<N>(t1, a, pa);                          // < 4p, limbs < 2^(B+1)
+  fe_select<N>(u, t1, t0, q == 0);
+  fe_sub<N>(t0, pb, b, F::BIAS2_L);
+  fe_add<N>(t1, b, pb);
+  fe_select<N>(v, t1, t0, q == 0);
+  if constexpr (F::B == 29) fe_carry<N, F::B>(u);   // as te_add: one operand of the 3 x 3 / 2 x 2 products
   // lane 2: Z1, Z2;  lane 3: k, T2
   Fe k;
-  fe_set(k, Bls12_377_Te::K2D);
-  fe_select(t0, a, k, q == 3);
-  fe_select(u, u, t0, q >= 2);
-  fe_select(v, v, b, q >= 2);
+  TeConst<F>::k2d(k);
+  fe_select<N>(t0, a, k, q == 3);
+  fe_select<N>(u, u, t0, q >= 2);
+  fe_select<N>(v, v, b, q >= 2);
   Fe r1, r2;
   fe_mul<F>(r1, u, v, md);                    // A | B | Z1 Z2 | k T2
   fe_mul<F>(r2, a, r1, md);                   // lane 3: C = T1 (k T2)
-  fe_select(r1, r1, r2, q == 3);
+  fe_select<N>(r1, r1, r2, q == 3);
   Fe A, B, C, D, Z;
-  fe_quad_perm<0x00>(A, r1);
-  fe_quad_perm<0x55>(B, r1);
-  fe_quad_perm<0xAA>(Z, r1);
-  fe_quad_perm<0xFF>(C, r1);
-  fe_dbl(D, Z);                               // < 3p, limbs < 2^29
+  fe_quad_perm<0x00, N>(A, r1);
+  fe_quad_perm<0x55, N>(B, r1);
+  fe_quad_perm<0xAA, N>(Z, r1);
+  fe_quad_perm<0xFF, N>(C, r1);
+  fe_dbl<N>(D, Z);                               // < 3p, limbs < 2^(B+1)
   Fe e, f, g, h;
-  fe_sub(e, B, A, F::BIAS2_28);               // as te_tail
-  fe_sub(f, D, C, F::BIAS2_28);
-  fe_add(g, D, C);
-  fe_add(h, B, A);
+  fe_sub<N>(e, B, A, F::BIAS2_L);               // as te_tail
+  fe_sub<N>(f, D, C, F::BIAS2_L);
+  fe_add<N>(g, D, C);
+  fe_add<N>(h, B, A);
+  if constexpr (F::B == 29) {
+    fe_carry<N, F::B>(f);
+    fe_carry<N, F::B>(h);
+  }
   // lane 0: E F   lane 1: G H   lane 2: F G   lane 3: E H
-  fe_select(u, e, g, q == 1);
-  fe_select(u, u, f, q == 2);
-  fe_select(v, h, f, q == 0);
-  fe_select(v, v, g, q == 2);
+  fe_select<N>(u, e, g, q == 1);
+  fe_select<N>(u, u, f, q == 2);
+  fe_select<N>(v, h, f, q == 0);
+  fe_select<N>(v, v, g, q == 2);
   fe_mul<F>(a, u, v, md);
 }
 #endif
@@ -285,5 +331,49 @@ MSM_HD bool fold_windows_te(Xyzz& out, const Xyzz* sums, int windows, int c, con
   return true;
 }
 
+// ---- between the limb shapes ---------------------------------------------------------------------------------------------
+// A canonical 14 x 28 record (what te_map_finish leaves) in the representation of F; the identity for F = Bls12_377_Fq.
+template <class F>
+MSM_HD void te_record_to(TeAffine& r, const TeAffine& a, const Modulus<F>& md) {
+  if constexpr (F::B == 29) {
+    fe_28_to_29(r.ymx, a.ymx, md);
+    fe_28_to_29(r.ypx, a.ypx, md);
+    fe_28_to_29(r.td, a.td, md);
+    // canonical, like the 14 x 28 records: equal points stay bit-identical and the bounds of te_madd start from < p
+    fe_reduce<F>(r.ymx);
+    fe_reduce<F>(r.ypx);
+    fe_reduce<F>(r.td);
+  } else {
+    r = a;
+  }
+}
+// An extended point held in the representation of F as a 14 x 28 point (class M): what te_to_sw / fold_windows_te and the host take.
+template <class F>
+MSM_HD void te_point_to_28(Xyzz& r, const Xyzz& a, const Modulus<Bls12_377_Fq>& md28) {
+  if constexpr (F::B == 29) {
+    fe_29_to_28(r.x, a.x, md28);
+    fe_29_to_28(r.y, a.y, md28);
+    fe_29_to_28(r.zz, a.zz, md28);
+    fe_29_to_28(r.zzz, a.zzz, md28);
+  } else {
+    r = a;
+  }
+}
+template <class F>
+MSM_HD void te_point_from_28(Xyzz& r, const Xyzz& a, const Modulus<F>& md) {
+  if constexpr (F::B == 29) {
+    Xyzz t = a;
+    fe_reduce<Bls12_377_Fq>(t.x);
+    fe_reduce<Bls12_377_Fq>(t.y);
+    fe_reduce<Bls12_377_Fq>(t.zz);
+    fe_reduce<Bls12_377_Fq>(t.zzz);
+    fe_28_to_29(r.x, t.x, md);
+    fe_28_to_29(r.y, t.y, md);
+    fe_28_to_29(r.zz, t.zz, md);
+    fe_28_to_29(r.zzz, t.zzz, md);
+  } else {
+    r = a;
+  }
+}
 
 }  // namespace msm
