@@ -1790,8 +1790,38 @@ RustError mi355_msm_query(mi355_msm_ctx* ctx, const char* key, uint64_t* value) 
         sum += v;
         all &= (v != 0);
       }
-      *value = (k == "twisted_edwards" || k == "assume_subgroup" || k == "carry") ? all
-                                                                                  : ((k == "table_levels" || k == "table_window_bits") ? sum / ctx->shards.size() : sum);
+      // (option-like and geometry keys are not counters -- every shard holds the same option, and a geometry key reports
+      //  the per-shard value (the largest, should the slices differ), not the sum over the shards)
+      static const char* const kAll[] = {"twisted_edwards", "assume_subgroup", "carry"};
+      static const char* const kMean[] = {"table_levels", "table_window_bits"};
+      static const char* const kFirst[] = {"precompute", "g2_paired", "guard_tail", "te_limb_bits"};
+      static const char* const kMax[] = {"bucket_windows", "l1_bits", "l1_bins", "group_passes", "top_split"};
+      auto in = [&](const char* const* set, size_t n) {
+        for (size_t i = 0; i < n; i++)
+          if (k == set[i]) return true;
+        return false;
+      };
+      if (in(kAll, 3)) {
+        *value = all;
+      } else if (in(kMean, 2)) {
+        *value = sum / ctx->shards.size();
+      } else if (in(kFirst, 4) || in(kMax, 5)) {
+        uint64_t first = 0, mx = 0;
+        for (size_t g = 0; g < ctx->shards.size(); g++) {
+          uint64_t v = 0;
+          RustError e = mi355_msm_query(ctx->shards[g], key, &v);
+          if (e.code) {
+            std::string m = e.message ? e.message : "";
+            free(e.message);
+            throw HipFailure(e.code, m);
+          }
+          if (g == 0) first = v;
+          mx = std::max(mx, v);
+        }
+        *value = in(kFirst, 4) ? first : mx;
+      } else {
+        *value = sum;
+      }
       return;
     }
     if (k == "twisted_edwards")
@@ -1834,6 +1864,8 @@ RustError mi355_msm_query(mi355_msm_ctx* ctx, const char* key, uint64_t* value) 
       *value = (uint64_t)ctx->opt_g2_paired;
     else if (k == "guard_tail")       // 1: MI355_MSM_GUARD_TAIL is on -- every device buffer ends at an unmapped page (DevBuf)
       *value = guard_tail_mode() ? 1 : 0;
+    else if (k == "te_limb_bits")     // bits per limb of the twisted-Edwards kernels' field (29: 13 x 29 limbs, 28: 14 x 28; csrc/te.hpp TeFq)
+      *value = (uint64_t)TeFq::B;
     else
       bad_arg("unknown query '%s'", key);
   });

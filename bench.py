@@ -846,6 +846,7 @@ def main():
     geom = {k: ctx.query(k) for k in ("bucket_windows", "l1_bits", "l1_bins", "group_passes")} if not c_sharded else None
     g2_paired = ctx.query("g2_paired") if (cid >= 2 and not c_sharded) else None
     ctx_levels = ctx.query("table_levels")
+    te_limb_bits = ctx.query("te_limb_bits")   # 29: the Edwards kernels run on 13 x 29-bit limbs (337 multiply-adds per product), 28: 14 x 28 (378)
 
     # measurements that borrow the headline context (its bases ARE the workload's), then its ONE close
     borrowed = {}
@@ -909,10 +910,10 @@ def main():
         # the integer roofline: lane-level v_mad_u64_u32 per second in the dominant kernel against the measured
         # issue peak of 1024 SIMDs x 64 lanes / 4.3 cycles at the nominal 2.4 GHz (profiles/r01_ubench_valu_*.txt).
         # v_mad_u64_u32 per mixed addition: a property of the formulas, pinned on the generated ISA by tests/test_isa.py -- 7 multiplications
-        # of 378 (Edwards); 6M + 2S + one fused dual product (XYZZ over Fp); G2 with two lanes per point: 10 fused dual products per lane
+        # of 337 (Edwards on 13 x 29 limbs; 378 on 14 x 28); 6M + 2S + one fused dual product (XYZZ over Fp); G2 with two lanes per point: 10 fused dual products per lane
         # (574 each with the p0 = 1 shortcut of BLS12-377, 588 for BLS12-381), i.e. 20 per addition; one lane per point: 8 x 2 + 2 x (1 + 2/3).
         paired = bool(g2_paired and (g2_paired & 1))
-        mads_per_add = {0: 2646 if ctx_te_path else 3416, 1: 3542, 2: 11480 if paired else 11088, 3: 11760 if paired else 11368}[cid]
+        mads_per_add = {0: ((2359 if te_limb_bits == 29 else 2646) if ctx_te_path else 3416), 1: 3542, 2: 11480 if paired else 11088, 3: 11760 if paired else 11368}[cid]
         adds_per_launch = tm["entries"]          # one mixed addition per sorted entry (zero digits are a ~1e-6 fraction)
         mad_rate = mads_per_add * adds_per_launch / kern_s
         mad_peak = 1024 * 64 / 4.3 * 2.4e9
@@ -941,7 +942,9 @@ def main():
             "scaling": "weak" if not total_npow else "strong",
             "vs_baseline": None,
             "dtype": "u32",
-            "dtype_detail": "14 x 28-bit limbs in u32 lanes, Montgomery radix 2^392, products accumulated in u64 (v_mad_u64_u32)",
+            "dtype_detail": ("13 x 29-bit limbs in u32 lanes, Montgomery radix 2^406 (twisted-Edwards kernels of BLS12-377 G1); " if (ctx_te_path and te_limb_bits == 29) else "")
+                            + "14 x 28-bit limbs in u32 lanes, Montgomery radix 2^392" + (" everywhere else" if (ctx_te_path and te_limb_bits == 29) else "")
+                            + "; products accumulated in u64 (v_mad_u64_u32)",
             "data": "synthetic: 2^15 distinct subgroup points replicated (reference generator shape), uniform scalars < r",
             "config": {"workload": (f"{args.curve} MSM, 2^{total_npow} pairs sharded over {n_ranks} GPU(s) (2^{args.npow} per GPU; "
                                     + ("BASELINE.json configs[3]" if (total_npow == 28 and n_ranks == 8) else "the shape of BASELINE.json configs[3] at another size")
@@ -988,6 +991,19 @@ def main():
                 except Exception as e:
                     extras[name] = {"error": repr(e)}
             out["survey_8d_metrics"] = extras
+            # SURVEY.md 8(d)'s primary figure at the TOP LEVEL.  `value` itself stays the device-resident rate: the
+            # task's measurement rule fixes it ("inputs already resident in HBM when the timed region starts ... the PCIe-inclusive
+            # rate ... is never `value`"); this object is the same MSM as the reference's timed closure sees it
+            # (P1A combined-top-solutions/benches/msm.rs:21,27-35: bases resident, scalars handed over in host memory).
+            hs = extras.get("host_scalars", {})
+            if "one_batch_ms" in hs:
+                out["host_scalars_ms_per_msm"] = {
+                    "pageable": hs["one_batch_ms"]["pageable"], "pinned": hs["one_batch_ms"]["pinned"],
+                    "four_batches_pageable": hs.get("four_batches_ms", {}).get("pageable"),
+                    "device_resident_ms": step_ms,
+                    "same_result": hs.get("same_result_as_device_scalars"),
+                    "what": "SURVEY 8(d) primary metric: one mi355_msm_run() with the 2^%d scalars in HOST memory (PCIe upload inside the call), bases resident; "
+                            "`value` / `ms_per_step` are the device-resident figure the measurement rule asks for" % args.npow}
         if single and args.extras and cid == 0 and args.npow == 26:
             out["secondary_configs"] = measure_secondary_configs(E)
             out["small_input_latency"] = measure_small_latency(E)
