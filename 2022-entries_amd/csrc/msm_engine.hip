@@ -17,7 +17,11 @@
 #include <dlfcn.h>
 
 #include <chrono>
+#include <condition_variable>
+#include <deque>
 #include <functional>
+#include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <thread>
 #include <type_traits>
@@ -302,6 +306,7 @@ struct mi355_msm_ctx {
   int device = 0;
   hipStream_t own_stream = nullptr;
   hipStream_t copy_stream = nullptr;   // H2D of the next scalar batch while the current one computes
+  struct AsyncWorker* async = nullptr; // mi355_msm_run_async: the context's worker thread and its job queue (created by the first job)
   hipEvent_t copy_ev[9] = {};   // batch parity 0/1 resident, pieces 0..6 of batch 0 resident
   size_t nbases = 0;
   DevBuf bases, inf;
@@ -1450,6 +1455,176 @@ void run_host(mi355_msm_ctx* ctx, void* out, const void* scalars, size_t n, size
 #include "msm_sharded.hpp"
 #include "msm_stateless.hpp"
 
+// ---- stream-ordered runs (mi355_msm_run_async) ---------------------------------------------------------------------------------
+// What the second-place entry's API offers a prover that overlaps MSMs with its other kernels (ML bellman-cuda.h:48-75: a stream,
+// events, host callbacks; used at P1A matter-labs/src/lib.rs:150-190): the call returns at once, the MSM is ordered after the work
+// already in the caller's stream, and completion is a callback.  An MSM ends in host arithmetic (the window fold) and has host-side
+// decisions on the way (out-of-memory back-off, the XYZZ repeat of an Edwards run that reported a vanishing denominator), none of which
+// may run inside a HIP host callback; so each context owns ONE worker thread that executes its jobs in submission order through the very
+// code path of mi355_msm_run_device, on the context's own stream, which first waits for an event recorded in the caller's stream.
+struct mi355_msm_job {
+  mi355_msm_ctx* ctx = nullptr;
+  void* out = nullptr;
+  const void* d_scalars = nullptr;
+  size_t npoints = 0, batches = 0;
+  hipEvent_t ready = nullptr;      // recorded in the caller's stream at submission: the scalars are valid from here on
+  mi355_msm_done_fn done = nullptr;
+  void* user = nullptr;
+  std::mutex mu;
+  std::condition_variable cv;
+  bool finished = false;
+  int code = 0;
+  std::string message;
+};
+
+struct AsyncWorker {
+  std::thread th;
+  std::mutex mu;
+  std::condition_variable cv;
+  std::deque<mi355_msm_job*> queue;
+  bool stop = false;
+  uint64_t submitted = 0, completed = 0;
+};
+
+namespace {
+
+void async_worker_main(mi355_msm_ctx* ctx) {
+  AsyncWorker* w = ctx->async;
+  for (;;) {
+    mi355_msm_job* job = nullptr;
+    {
+      std::unique_lock<std::mutex> lk(w->mu);
+      w->cv.wait(lk, [&] { return w->stop || !w->queue.empty(); });
+      if (w->queue.empty()) return;   // stop, and nothing left to run
+      job = w->queue.front();
+      w->queue.pop_front();
+    }
+    RustError e = guarded_dev([&] {
+      (void)require_device();
+      if (ctx->shards.empty()) {
+        ensure_device(ctx);
+        // ordered after the caller's stream WITHOUT blocking a host thread on it: the context's stream waits for the event
+        HIP_OK(hipStreamWaitEvent(ctx->own_stream, job->ready, 0));
+        run_device(ctx, job->out, job->d_scalars, job->npoints, job->batches, job->npoints, ctx->own_stream);
+      } else {
+        HIP_OK(hipEventSynchronize(job->ready));   // the shards run on their own devices and streams
+        sharded_run(ctx, job->out, job->d_scalars, job->npoints, job->batches, true, nullptr);
+      }
+    });
+    {
+      std::lock_guard<std::mutex> lk(w->mu);
+      w->completed++;
+    }
+    // the callback sees the finished job state; its RustError is the callback's to free (rusterror.h convention)
+    {
+      std::lock_guard<std::mutex> lk(job->mu);
+      job->code = e.code;
+      job->message = e.message ? e.message : "";
+    }
+    if (job->done) {
+      RustError cb{e.code, e.message ? strdup(e.message) : nullptr};
+      job->done(job->user, cb);
+    }
+    if (e.message) free(e.message);
+    {
+      std::lock_guard<std::mutex> lk(job->mu);
+      job->finished = true;
+    }
+    job->cv.notify_all();
+  }
+}
+
+void async_shutdown(mi355_msm_ctx* ctx) {
+  AsyncWorker* w = ctx->async;
+  if (!w) return;
+  {
+    std::lock_guard<std::mutex> lk(w->mu);
+    w->stop = true;
+  }
+  w->cv.notify_all();
+  if (w->th.joinable()) w->th.join();   // (pending jobs are run to completion first: their callers hold pointers to them)
+  delete w;
+  ctx->async = nullptr;
+}
+
+}  // namespace
+
+extern "C" {
+
+RustError mi355_msm_run_async(mi355_msm_ctx* ctx, void* out, const void* d_scalars, size_t npoints, size_t batches, void* stream,
+                              mi355_msm_done_fn done, void* user, mi355_msm_job** job_out) {
+  return guarded_dev([&] {
+    if (!ctx) bad_arg("null context");
+    if (!out) bad_arg("null output pointer");
+    if (!job_out && !done) bad_arg("neither a job handle nor a completion callback was asked for: the result could never be awaited");
+    if (npoints * batches && !d_scalars) bad_arg("null scalars pointer");
+    if (job_out) *job_out = nullptr;
+    (void)require_device();
+    if (ctx->shards.empty()) {
+      ensure_device(ctx);
+      if (npoints > ctx->nbases) bad_arg("npoints %zu exceeds the %zu uploaded bases", npoints, ctx->nbases);
+    }
+    std::unique_ptr<mi355_msm_job> job(new mi355_msm_job());
+    job->ctx = ctx;
+    job->out = out;
+    job->d_scalars = d_scalars;
+    job->npoints = npoints;
+    job->batches = batches;
+    job->done = done;
+    job->user = user;
+    HIP_OK(hipEventCreateWithFlags(&job->ready, hipEventDisableTiming));
+    hipError_t er = hipEventRecord(job->ready, (hipStream_t)stream);
+    if (er != hipSuccess) {
+      (void)hipEventDestroy(job->ready);
+      HIP_OK(er);
+    }
+    if (!ctx->async) {
+      ctx->async = new AsyncWorker();
+      ctx->async->th = std::thread(async_worker_main, ctx);
+    }
+    mi355_msm_job* raw = job.release();
+    {
+      std::lock_guard<std::mutex> lk(ctx->async->mu);
+      ctx->async->queue.push_back(raw);
+      ctx->async->submitted++;
+    }
+    ctx->async->cv.notify_one();
+    if (job_out) {
+      *job_out = raw;
+    } else {
+      // fire-and-forget (callback only): the job object is released by a watcher once it has finished
+      std::thread([raw] {
+        {
+          std::unique_lock<std::mutex> lk(raw->mu);
+          raw->cv.wait(lk, [&] { return raw->finished; });
+        }
+        (void)hipEventDestroy(raw->ready);
+        delete raw;
+      }).detach();
+    }
+  });
+}
+
+int mi355_msm_job_done(mi355_msm_job* job) {
+  if (!job) return 1;
+  std::lock_guard<std::mutex> lk(job->mu);
+  return job->finished ? 1 : 0;
+}
+
+RustError mi355_msm_job_wait(mi355_msm_job* job) {
+  if (!job) return fail(-1, "null job");
+  {
+    std::unique_lock<std::mutex> lk(job->mu);
+    job->cv.wait(lk, [&] { return job->finished; });
+  }
+  RustError e = job->code ? fail(job->code, job->message.c_str()) : ok();
+  (void)hipEventDestroy(job->ready);
+  delete job;
+  return e;
+}
+
+}  // extern "C"
+
 extern "C" {
 
 RustError mi355_msm_create(mi355_msm_ctx** out, int curve, int device) {
@@ -1477,6 +1652,7 @@ RustError mi355_msm_create(mi355_msm_ctx** out, int curve, int device) {
 }
 
 RustError mi355_msm_destroy(mi355_msm_ctx* ctx) {
+  if (ctx) async_shutdown(ctx);   // (outside the guard: joins the worker, which runs pending jobs to completion)
   return guarded_dev([&] {
     if (!ctx) return;
     if (!ctx->shards.empty()) {
@@ -1774,6 +1950,15 @@ RustError mi355_msm_query(mi355_msm_ctx* ctx, const char* key, uint64_t* value) 
     }
     if (k == "peer_stagings") {
       *value = ctx->peer_stagings;
+      return;
+    }
+    if (k == "async_pending") {   // jobs of mi355_msm_run_async submitted and not yet finished
+      uint64_t v = 0;
+      if (ctx->async) {
+        std::lock_guard<std::mutex> lk(ctx->async->mu);
+        v = ctx->async->submitted - ctx->async->completed;
+      }
+      *value = v;
       return;
     }
     if (!ctx->shards.empty()) {

@@ -92,6 +92,8 @@ def load_library() -> ctypes.CDLL:
         "mi355_msm_set_bases_device": [vp, vp, sz, sz],
         "mi355_msm_run": [vp, vp, vp, sz, sz],
         "mi355_msm_run_device": [vp, vp, vp, sz, sz, vp],
+        "mi355_msm_run_async": [vp, vp, vp, sz, sz, vp, vp, vp, ctypes.POINTER(vp)],
+        "mi355_msm_job_wait": [vp],
         "mi355_msm_set_option": [vp, ctypes.c_char_p, ctypes.c_long],
         "mi355_msm_last_timings": [vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_uint64)],
         "mi355_msm_query": [vp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_uint64)],
@@ -117,6 +119,8 @@ def load_library() -> ctypes.CDLL:
         fn.argtypes = args
         fn.restype = _RustError
     lib.mi355_msm_version.restype = ctypes.c_char_p
+    lib.mi355_msm_job_done.argtypes = [vp]
+    lib.mi355_msm_job_done.restype = ci
     _LIB = lib
     return lib
 
@@ -262,6 +266,27 @@ class MultiScalarMultContext:
             _check(self._lib.mi355_msm_run(self.context, out, b.ptr, n, batches))
         raw = out.raw
         return [raw[i * pb:(i + 1) * pb] for i in range(batches)]
+
+    def run_async(self, scalars, npoints: Optional[int] = None, stream=None) -> "MsmJob":
+        """Stream-ordered run (mi355_msm_run_async; the role of ML bellman-cuda.h:48-75 msm_execute_async): returns at once with a job
+        handle.  ``scalars`` must be a device tensor; the MSM is ordered after the work already enqueued in ``stream`` (default: the
+        tensor's current torch stream) and runs on the context's own stream, so whatever the caller launches next overlaps it.
+        ``job.wait()`` returns the projective images; jobs of one context run in submission order."""
+        b = _Buf(scalars)
+        if not b.is_device:
+            raise TypeError("run_async takes scalars that are resident on the device (use run() for host scalars)")
+        self._check_device(b, "scalars")
+        n = self.npoints if npoints is None else npoints
+        count = b.nbytes // SCALAR_BYTES
+        if b.nbytes % SCALAR_BYTES or n == 0 or count % n:
+            raise ValueError(f"{count} scalars is not a whole number of batches of {n} points")
+        batches = count // n
+        pb = projective_bytes(self.curve)
+        out = ctypes.create_string_buffer(pb * batches)
+        job = ctypes.c_void_p()
+        st = b.stream if stream is None else (stream.cuda_stream if hasattr(stream, "cuda_stream") else stream)
+        _check(self._lib.mi355_msm_run_async(self.context, out, b.ptr, n, batches, st, None, None, ctypes.byref(job)))
+        return MsmJob(self._lib, job, out, pb, batches, b)
 
     def set_option(self, key: str, value: int) -> None:
         _check(self._lib.mi355_msm_set_option(self.context, key.encode(), int(value)))
@@ -496,6 +521,35 @@ def generate_points(npoints: int, distinct: int = 1 << 15, seed: int = 0x5A50524
     out = np.zeros((npoints, stride), dtype=np.uint8)
     _check(lib.mi355_msm_generate_points(_curve_id(curve), seed, distinct, npoints, out.ctypes.data, stride))
     return out
+
+
+class MsmJob:
+    """A run in flight (MultiScalarMultContext.run_async).  Keeps the scalars and the output buffer alive until it is waited for."""
+
+    def __init__(self, lib, handle, out, pb, batches, keep):
+        self._lib, self._handle, self._out, self._pb, self._batches, self._keep = lib, handle, out, pb, batches, keep
+        self._result = None
+
+    def done(self) -> bool:
+        return self._handle is None or bool(self._lib.mi355_msm_job_done(self._handle))
+
+    def wait(self) -> List[bytes]:
+        if self._handle is not None:
+            h, self._handle = self._handle, None
+            _check(self._lib.mi355_msm_job_wait(h))      # (releases the handle, whatever the status)
+            raw = self._out.raw
+            self._result = [raw[i * self._pb:(i + 1) * self._pb] for i in range(self._batches)]
+            self._keep = None
+        if self._result is None:
+            raise MsmError(-1, "this job failed (its error was raised by the first wait())")
+        return self._result
+
+    def __del__(self):
+        try:
+            if self._handle is not None:
+                self.wait()
+        except Exception:
+            pass
 
 
 def plan(npoints: int, curve="bls12_377_g1", precompute: bool = False, window_bits: int = 0, lane_entries: int = 0,

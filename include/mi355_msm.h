@@ -117,6 +117,29 @@ RustError mi355_msm_run(mi355_msm_ctx* ctx, void* out_projective, const void* sc
 RustError mi355_msm_run_device(mi355_msm_ctx* ctx, void* out_projective, const void* d_scalars, size_t npoints,
                                size_t batches, void* stream);
 
+/* ---- stream-ordered run -------------------------------------------------------------------------------------------------
+ * Replaces the asynchronous half of the second-place entry's API: msm_configuration.stream, h2d_copy_finished{,_callback},
+ * d2h_copy_finished{,_callback} and msm_execute_async (ML bellman-cuda.h:48-75, ML msm.cu:97-468; caller:
+ * P1A matter-labs/src/lib.rs:150-190), which lets a prover keep its own kernels (NTTs) running while an MSM is in flight.
+ *
+ * mi355_msm_run_async returns as soon as the job is queued (no device synchronisation in the calling thread).  The MSM is ordered
+ * AFTER everything enqueued in `stream` before the call (an event is recorded there; `d_scalars` must be valid from that point
+ * until the job has finished) and runs on the context's own stream, so work the caller enqueues on ANY of its streams afterwards
+ * overlaps it.  Jobs of one context run one after the other in submission order, on a worker thread the context owns -- the tail
+ * of an MSM is host arithmetic (window fold, normalisation) and host decisions (out-of-memory back-off, the XYZZ repeat of an
+ * Edwards run), which is why completion is a host-side event: `done(user, status)` is called from that thread once
+ * `out_projective` (HOST memory, `batches` images) is written -- status.code 0 = success; status.message, if any, is the callback's
+ * to free() (SPK util/rusterror.h:15-27) -- and / or the job handle can be polled and waited for.  At least one of `done` and `job`
+ * must be given.  mi355_msm_job_wait blocks until the job has finished, returns its status and RELEASES the handle (call it
+ * exactly once per handle); mi355_msm_job_done polls (1 = finished).  The synchronous entry points of the same context must not be
+ * called while jobs are pending (query "async_pending"); mi355_msm_destroy runs pending jobs to completion first. */
+typedef struct mi355_msm_job mi355_msm_job;
+typedef void (*mi355_msm_done_fn)(void* user, RustError status);
+RustError mi355_msm_run_async(mi355_msm_ctx* ctx, void* out_projective, const void* d_scalars, size_t npoints, size_t batches,
+                              void* stream, mi355_msm_done_fn done, void* user, mi355_msm_job** job);
+int mi355_msm_job_done(mi355_msm_job* job);
+RustError mi355_msm_job_wait(mi355_msm_job* job);
+
 /* "precompute" = 2 (auto, set BEFORE set_bases): the context picks the table levels itself from the device memory that is free at
  * set_bases -- a level per window, else 6, 4 or 3 levels (the shapes profiles/r04_table_levels_sweep.txt shows as wins: -6 % / -3 % /
  * -1.4 % / -1 % at 2^26 pairs), each only if it fits with its build temporaries and leaves the work buffers of a full chunk plus a

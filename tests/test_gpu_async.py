@@ -1,0 +1,135 @@
+"""GPU: the stream-ordered run (mi355_msm_run_async, include/mi355_msm.h) -- what the second-place entry's msm_execute_async offers a
+prover that keeps other kernels running (ML bellman-cuda.h:48-75; P1A matter-labs/src/lib.rs:150-190): the call returns at once, the
+MSM is ordered after the caller's stream, other streams overlap it, completion is host-side (callback / handle), results are those
+of the synchronous path (oracle-pinned by tests/test_gpu_parity.py) and, at a size the oracle finishes, the oracle's."""
+import ctypes
+import threading
+import time
+
+import numpy as np
+import pytest
+
+import pymodel as m
+from conftest import oracle_msm_np
+from test_gpu_parity import rand_scalars_np
+
+pytestmark = pytest.mark.gpu
+
+
+def test_async_result_is_the_oracles(ea, oracle):
+    import torch
+
+    curve = m.BLS12_377_G1
+    n = 1 << 14
+    bases = ea.generate_points(n, distinct=1 << 10, seed=3, curve=curve.name)
+    scalars = rand_scalars_np(0, 2 * n, 41)
+    ctx = ea.multi_scalar_mult_init(torch.from_numpy(bases).cuda(), curve.name)
+    job = ctx.run_async(torch.from_numpy(scalars).cuda())
+    got = job.wait()
+    assert job.done() and len(got) == 2
+    for b in range(2):
+        assert got[b] == oracle_msm_np(oracle, 0, bases, np.ascontiguousarray(scalars[b * n:(b + 1) * n]), n)
+    assert ctx.query("async_pending") == 0
+    with pytest.raises(TypeError):
+        ctx.run_async(scalars)           # host scalars: the synchronous entry point is the one that uploads
+    ctx.close()
+
+
+def test_async_call_returns_at_once_and_other_streams_overlap(ea):
+    import torch
+
+    curve = m.BLS12_377_G1
+    n = 1 << 24
+    tile = torch.from_numpy(ea.generate_points(1 << 15, distinct=1 << 15, seed=9, curve=curve.name)).cuda()
+    ctx = ea.multi_scalar_mult_init(tile.repeat(n >> 15, 1).contiguous(), curve.name)
+    scalars = torch.from_numpy(rand_scalars_np(0, n, 5)).cuda()
+    ref = ctx.run(scalars)[0]                      # warm: buffers, code objects; and the reference bytes
+    t_sync = time.perf_counter()
+    assert ctx.run(scalars)[0] == ref
+    t_sync = time.perf_counter() - t_sync          # ~30 ms
+
+    # the caller's own work: element-wise kernels on ANOTHER stream (no LDS: they fit beside the accumulation's blocks, whose three
+    # per CU hold 156 of the 160 KB -- a kernel that needs LDS of its own waits for a block to retire, up to ~10 ms at this size)
+    side = torch.cuda.Stream()
+    a = torch.zeros(1 << 24, device="cuda")
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            a.add_(1.0)                             # warm
+    torch.cuda.synchronize()
+
+    t0 = time.perf_counter()
+    job = ctx.run_async(scalars)
+    t_call = time.perf_counter() - t0
+    assert t_call < 1e-3, f"mi355_msm_run_async took {t_call * 1e3:.2f} ms to return"
+    assert not job.done()                          # tens of milliseconds of MSM are in flight
+    e1 = torch.cuda.Event()
+    with torch.cuda.stream(side):
+        for _ in range(40):
+            a.add_(1.0)
+        e1.record()
+    e1.synchronize()
+    t_side_done = time.perf_counter() - t0
+    still_running = not job.done()
+    got = job.wait()
+    t_total = time.perf_counter() - t0
+    assert got[0] == ref
+    assert float(a[0]) == 43.0 and float(a[-1]) == 43.0
+    # the side stream's kernels ran WHILE the MSM was in flight: they were done before it was, and the pair cost no more than the MSM
+    # alone plus a margin (run one after the other they would add up)
+    assert still_running, (t_side_done, t_total, t_sync)
+    assert t_total < 1.25 * t_sync, (t_total, t_sync)
+
+    # ordering after the caller's stream: scalars produced by a kernel enqueued just before the call
+    prod = torch.cuda.Stream()
+    with torch.cuda.stream(prod):
+        late = torch.zeros_like(scalars)
+        for _ in range(10):
+            late.copy_(scalars ^ 0xFF)              # keep the stream busy ...
+        late.copy_(scalars)                         # ... the real values arrive last
+        job2 = ctx.run_async(late)
+    assert job2.wait()[0] == ref
+    # several jobs queue up and finish in order
+    jobs = [ctx.run_async(scalars) for _ in range(3)]
+    assert ctx.query("async_pending") >= 1
+    assert all(j.wait()[0] == ref for j in jobs)
+    ctx.close()
+
+
+def test_async_callback_and_errors_through_the_c_abi(ea):
+    """done(user, status) is called from the context's worker thread once the output is written; a bad job is reported at submission."""
+    import torch
+
+    lib = ea.load_library()
+    curve = m.BLS12_381_G1
+    n = 1 << 12
+    bases = torch.from_numpy(ea.generate_points(n, distinct=64, seed=2, curve=curve.name)).cuda()
+    ctx = ea.multi_scalar_mult_init(bases, curve.name)
+    scalars = torch.from_numpy(rand_scalars_np(1, n, 8)).cuda()
+    ref = ctx.run(scalars)[0]
+    out = ctypes.create_string_buffer(144)
+    fired = threading.Event()
+    seen = {}
+
+    class RustError(ctypes.Structure):
+        _fields_ = [("code", ctypes.c_int), ("message", ctypes.c_void_p)]
+
+    CB = ctypes.CFUNCTYPE(None, ctypes.c_void_p, RustError)
+
+    def done(user, status):
+        seen["user"], seen["code"], seen["out"] = user, status.code, out.raw
+        fired.set()
+
+    cb = CB(done)
+    err = lib.mi355_msm_run_async(ctx.context, out, scalars.data_ptr(), n, 1, torch.cuda.current_stream().cuda_stream, ctypes.cast(cb, ctypes.c_void_p), 1234, None)
+    assert err.code == 0
+    assert fired.wait(30)
+    assert seen == {"user": 1234, "code": 0, "out": ref}
+    # neither a handle nor a callback: refused; more points than bases: refused at submission
+    job = ctypes.c_void_p()
+    for args in ((ctx.context, out, scalars.data_ptr(), n, 1, None, None, None, None),
+                 (ctx.context, out, scalars.data_ptr(), 2 * n, 1, None, None, None, ctypes.byref(job))):
+        err = lib.mi355_msm_run_async(*args)
+        assert err.code != 0 and err.message
+        ctypes.CDLL(None).free(ctypes.c_void_p(err.message))
+    ctx.close()
