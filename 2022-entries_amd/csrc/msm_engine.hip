@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string.h>
+#include <strings.h>
 
 #include <dlfcn.h>
 
@@ -700,7 +701,17 @@ void build_te(mi355_msm_ctx* ctx, size_t n, hipStream_t st) {
 // tried largest first; each must fit with its build temporaries AND leave the work buffers of a full chunk plus a tenth of the device to
 // the caller.  -1 = no tables (small inputs, where tables were never measured to pay, or not enough memory: none under ~64 GB free at 2^26).
 int precompute_auto_levels(mi355_msm_ctx* ctx, size_t n) {
-  if (n < ((size_t)1 << 24)) return -1;
+  // Below 2^24 pairs (round 6, profiles/r06_size_sweep_tables.txt): where the bucket reduction and the fragment merge are a quarter of
+  // an MSM, SIX levels -- a window size of 16..17 bits with 3 bucket sets instead of 17..24 -- pay at least 5 %:
+  //   BLS12-377 G1  2^18 -7.5 %, 2^19 -13.7 %, 2^20 -6.1 % (2^21 -3.3 %: left alone, 2^22..2^23: tables lose)
+  //   BLS12-381 G1  2^18 -23 %, 2^19 -20 %   (from 2^20 on tables lose)
+  //   G2            2^18 -18 %, 2^19 -22 %, 2^20 -15.5 %, 2^21 -7.8 %   (2^22: +-0)
+  // for 0.2 .. 3.2 GB of tables and 20 .. 230 ms of (untimed) init.  Nothing was measured below 2^18: no tables there.
+  const bool mid = n < ((size_t)1 << 24);
+  if (mid) {
+    const size_t upper = is_g2(ctx->curve) ? ((size_t)3 << 20) : (is_381(ctx->curve) ? ((size_t)3 << 18) : ((size_t)3 << 19));
+    if (n < ((size_t)1 << 18) || n >= upper) return -1;
+  }
   size_t free_b = 0, total_b = 0;
   HIP_OK(hipMemGetInfo(&free_b, &total_b));
   size_t held = ctx->bases.bytes + ctx->te_bases.bytes + ctx->inf.bytes, nb = 0;
@@ -712,7 +723,13 @@ int precompute_auto_levels(mi355_msm_ctx* ctx, size_t n) {
   if (ctx->opt_mem_limit > 0 && (uint64_t)ctx->opt_mem_limit < avail) avail = (uint64_t)ctx->opt_mem_limit;   // (test hook)
   const uint64_t el = is_g2(ctx->curve) ? 2 : 1;
   const bool te = ctx->curve == MI355_BLS12_377_G1 && ctx->opt_twisted_edwards;
-  for (int want : {0, 6, 4, 3}) {
+  // candidates, largest first: G1 {all, 6, 4, 3} (each a measured win at 2^26: profiles/r04_table_levels_sweep.txt); G2 {all, 6} only --
+  // 3 levels LOSE there (115.5 ms against 111.4 without tables, profiles/r05_g2_tables_and_window.txt)
+  static const int kG1[] = {0, 6, 4, 3}, kG2[] = {0, 6}, kMid[] = {6};
+  const int* cand = mid ? kMid : (el == 2 ? kG2 : kG1);
+  const int ncand = mid ? 1 : (el == 2 ? 2 : 4);
+  for (int ci = 0; ci < ncand; ci++) {
+    const int want = cand[ci];
     const TableShape ts = table_shape(n, ctx->scalar_bits(), ctx->opt_window_bits, want);
     if (want > 0 && ts.levels > (uint32_t)want) continue;
     if ((uint64_t)ts.levels * n >= (1ull << 31) || ts.levels < 2) continue;
@@ -721,10 +738,16 @@ int precompute_auto_levels(mi355_msm_ctx* ctx, size_t n) {
     // peak of the build: the streamed Edwards build holds three short-Weierstrass levels, every Edwards level and one XYZZ + prefix array
     // (build_tables_te_streamed); the plain build every level and the same temporaries
     const uint64_t build = te ? 3 * n * 128 + te_b + n * (224 + 56) : sw + n * (224 + 56) * el;
-    mi355_msm_ctx tmp;   // (planning arithmetic only)
+    mi355_msm_ctx tmp;   // (planning arithmetic only; the options that shape a plan are the context's)
     tmp.curve = ctx->curve;
     tmp.pre_c = ts.c;
     tmp.pre_windows = ts.levels;
+    tmp.opt_window_bits = ctx->opt_window_bits;
+    tmp.opt_assume_subgroup = ctx->opt_assume_subgroup;
+    tmp.opt_lane_entries = ctx->opt_lane_entries;
+    tmp.opt_seg_entries = ctx->opt_seg_entries;
+    tmp.opt_reduce_scan = ctx->opt_reduce_scan;
+    tmp.opt_reduce_fill = ctx->opt_reduce_fill;
     const Plan p = tmp.plan(std::min(n, (size_t)1 << 26));
     const uint64_t steady = (te ? n * 128 * el + te_b : sw) + inf + work_bytes(p, el) + n * 32;
     const uint64_t need = std::max(build + inf, steady);
@@ -755,7 +778,7 @@ bool build_tables_te_streamed(mi355_msm_ctx* ctx, const uint8_t* d_raw, size_t n
   HIP_OK(hipMemGetInfo(&free_b, &total_b));
   if (need > free_b + ctx->bases.bytes + ctx->te_bases.bytes + ctx->inf.bytes)
     bad_arg("precompute: %u table levels of %zu points need %zu MiB, only %zu MiB free", levels, n, need >> 20, free_b >> 20);
-  DevBuf xyzz, prefix;
+  DevBuf xyzz, prefix, level0;   // (all three released on every path out: DevBuf has no destructor)
   bool ok = false;
   try {
     ctx->te_bases.reserve((size_t)levels * n * sizeof(TeAffineDev));
@@ -783,16 +806,17 @@ bool build_tables_te_streamed(mi355_msm_ctx* ctx, const uint8_t* d_raw, size_t n
     ok = ctx->h_flags[0] == 0;
     if (ok) {
       // keep level 0 of the short-Weierstrass form only: it serves the (rare) XYZZ fallback, without tables
-      DevBuf level0;
       level0.reserve(n * sizeof(AffineDev));
       HIP_OK(hipMemcpyAsync(level0.p, ctx->bases.p, n * sizeof(AffineDev), hipMemcpyDeviceToDevice, st));
       HIP_OK(hipStreamSynchronize(st));   // (a device-to-device hipMemcpy is not host-synchronous: the source is freed next)
       ctx->bases.release();
       ctx->bases = level0;
+      level0 = DevBuf{};   // (ownership moved)
     }
   } catch (...) {
     xyzz.release();
     prefix.release();
+    level0.release();
     ctx->te_bases.release();
     throw;
   }
@@ -821,6 +845,12 @@ void set_bases_device(mi355_msm_ctx* ctx, const void* d_affine, size_t n, size_t
   ctx->te_fallback_streak = 0;
   ctx->sw_level0_only = false;
   ctx->auto_levels = 0;
+  // The buffers of the PREVIOUS base set go back first: DevBuf::reserve only grows, so a second set_bases used to keep the
+  // larger of the two allocations (tables of 150 GB behind a table-free context), precompute_auto_levels counted that memory as free
+  // although te_bases is reserved while the old bases are still allocated, and "base_bytes" reported the old size.
+  ctx->bases.release();
+  ctx->te_bases.release();
+  ctx->inf.release();
   bool te_done = false;   // the Edwards records were built together with the tables (build_tables_te_streamed)
   if (n) {
     bool tables = ctx->opt_precompute == 1;
@@ -1713,7 +1743,14 @@ RustError mi355_msm_create_env(mi355_msm_ctx** out, int curve) {
   // MI355_MSM_PRECOMPUTE = auto | 0 | 1 (+ MI355_MSM_TABLE_LEVELS = k): the harness's init is untimed (CMB MSM.cu:380-383 builds its
   // tables there), so a harness that owns the GPU may let the context spend free HBM on tables -- options "precompute" / "table_levels"
   const char* pre = getenv("MI355_MSM_PRECOMPUTE");
-  if (!e.code && pre && *pre) e = mi355_msm_set_option(*out, "precompute", strcmp(pre, "auto") == 0 ? 2 : (atol(pre) != 0 ? 1 : 0));
+  if (!e.code && pre && *pre) {
+    // auto | 0 | 1, case-insensitive; anything else is refused rather than guessed ("AUTO" used to mean 0 and "2" to mean 1)
+    long v = -1;
+    if (strcasecmp(pre, "auto") == 0) v = 2;
+    else if (strcmp(pre, "0") == 0 || strcasecmp(pre, "off") == 0) v = 0;
+    else if (strcmp(pre, "1") == 0 || strcasecmp(pre, "on") == 0) v = 1;
+    e = v >= 0 ? mi355_msm_set_option(*out, "precompute", v) : fail(-1, "MI355_MSM_PRECOMPUTE must be auto, 0 or 1");
+  }
   const char* lv = getenv("MI355_MSM_TABLE_LEVELS");
   if (!e.code && lv && *lv) e = mi355_msm_set_option(*out, "table_levels", atol(lv));
   if (e.code) {

@@ -143,7 +143,9 @@ RustError mi355_msm_job_wait(mi355_msm_job* job);
 /* "precompute" = 2 (auto, set BEFORE set_bases): the context picks the table levels itself from the device memory that is free at
  * set_bases -- a level per window, else 6, 4 or 3 levels (the shapes profiles/r04_table_levels_sweep.txt shows as wins: -6 % / -3 % /
  * -1.4 % / -1 % at 2^26 pairs), each only if it fits with its build temporaries and leaves the work buffers of a full chunk plus a
- * tenth of the device to the caller; none below 2^24 pairs or when memory is short (about 64 GB free at 2^26), and a build that
+ * tenth of the device to the caller; between 2^18 pairs and 2^20 (BLS12-377 G1), 2^19 (BLS12-381 G1), 2^21 (G2) six levels, where
+ * they are worth 6 - 23 % (profiles/r06_size_sweep_tables.txt); none at the sizes in between, below 2^18, or when memory is short
+ * (about 64 GB free at 2^26), and a build that
  * fails all the same leaves the context on the table-free path.  mi355_msm_query "table_levels" says what it chose.  The harness
  * shims take it from the environment: MI355_MSM_PRECOMPUTE=auto|0|1 (the reference's init builds its tables untimed,
  * CMB MSM.cu:380-383).
@@ -270,7 +272,9 @@ RustError mi355_msm_generate_points(int curve, uint64_t seed, size_t distinct, s
  * fragment-merge launches, bucket-reduce launches, sort key bits, bytes of per-run device work buffers.
  * `options` may be NULL or {window_bits, lane_entries, seg_entries} (0 = automatic).  `precompute`: 0 = no tables, 1 = a table
  * level per window, k > 1 = the context option "table_levels" = k -- the plan then equals what a context with those options
- * reports through mi355_msm_query "table_window_bits" / "table_levels". */
+ * reports through mi355_msm_query "table_window_bits" / "table_levels".
+ * NOTE: this argument is a LEVEL COUNT, not the context option "precompute" (where 2 means "auto"): passing that option's value here
+ * plans two table levels.  To plan what an auto context runs, query its "table_levels" after set_bases and pass that. */
 RustError mi355_msm_plan(int curve, size_t npoints, int precompute, const long* options, uint64_t* out);
 
 /* The slice [*lo, *hi) of range(npoints) that shard `shard` of `nshards` owns in a sharded context (and in dist.py's

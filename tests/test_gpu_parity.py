@@ -374,7 +374,9 @@ def test_precompute_auto(ea, oracle, torch_cuda, curve_name, cid, rid):
     seen = []
     ctx = ea.MultiScalarMultContext(curve_name)
     ctx.set_option("precompute", 2)
-    for limit_gb in (0, 40, 24, 3):           # 0 = no limit: the whole (otherwise idle) device
+    # every branch is driven through the test hook "mem_limit" (an upper bound on what the context may count as free), never through
+    # what happens to be free on the box: 100 GB pays for a level per window at this size, 40 / 24 GB for fewer, 3 GB for none
+    for limit_gb in (100, 40, 24, 3):
         ctx.set_option("mem_limit", limit_gb << 30)
         ctx.set_bases(bases)
         levels = ctx.query("table_levels")
@@ -389,6 +391,33 @@ def test_precompute_auto(ea, oracle, torch_cuda, curve_name, cid, rid):
     ctx.set_bases(bases)
     assert ctx.query("table_levels") == 1
     assert ctx.run(scal)[0] == ref
+    ctx.close()
+
+
+@pytest.mark.parametrize("curve_name,cid,rid,npow,expect", [("bls12_377_g1", 0, 0, 18, 6), ("bls12_377_g1", 0, 0, 20, 6), ("bls12_377_g1", 0, 0, 21, 1),
+                                                             ("bls12_381_g1", 1, 1, 19, 6), ("bls12_381_g1", 1, 1, 20, 1),
+                                                             ("bls12_377_g2", 2, 0, 18, 6), ("bls12_377_g2", 2, 0, 22, 1)])
+def test_precompute_auto_at_mid_sizes(ea, oracle, torch_cuda, curve_name, cid, rid, npow, expect):
+    """ "precompute" = 2 between 2^18 pairs and the per-curve upper bound takes SIX table levels (round 6: 6 - 23 % there,
+    profiles/r06_size_sweep_tables.txt; the reference's own shape is 6 levels, CMB PrecomputePoints.cu:10-39), none just above the
+    bound; the bytes are those of the table-free context, which the oracle pins at 2^18 on G1."""
+    torch = torch_cuda
+    n = 1 << npow
+    tile = ea.generate_points(1 << 12, distinct=1 << 12, seed=18, curve=curve_name)
+    bases = torch.from_numpy(tile).cuda().repeat(n >> 12, 1).contiguous()
+    scal = torch.from_numpy(rand_scalars_np(rid, n, 19)).cuda()
+    plain = ea.MultiScalarMultContext(curve_name)
+    plain.set_bases(bases)
+    ref = plain.run(scal)[0]
+    plain.close()
+    if cid < 2 and npow == 18:
+        assert ref == oracle_msm_np(oracle, cid, np.ascontiguousarray(np.tile(tile, (n >> 12, 1))), scal.cpu().numpy(), n)
+    ctx = ea.MultiScalarMultContext(curve_name)
+    ctx.set_option("precompute", 2)
+    ctx.set_bases(bases)
+    assert ctx.query("table_levels") == expect, (curve_name, npow, ctx.query("table_levels"))
+    assert ctx.run(scal)[0] == ref
+    assert ctx.last_timings()["tables"] == (expect > 1)
     ctx.close()
 
 
