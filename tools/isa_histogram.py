@@ -101,20 +101,31 @@ def loop_histogram(body):
     if best is None:
         raise RuntimeError("no loop found")
     _, lo, hi = best
-    # cold blocks: ranges jumped over by a forward conditional branch (s_cbranch_execz / vccz ... to a later label inside the loop) that hold a
-    # multiply-add -- the same-x branch of the short-Weierstrass law.  Everything else in [lo, hi) is the trip.
-    cold = [False] * len(instrs)
+    # cold blocks.  Forward conditional branches that skip a range holding multiply-adds delimit the whole addition under
+    # `if (add_now)`, the general case under `if (!fresh)` ... -- ranges that hold (nearly) all the multiply-adds of the range around them:
+    # HOT -- and the exceptional paths: the same-x branch of the short-Weierstrass laws (doubling / cancellation, taken ~never on random
+    # input; somewhat fewer multiply-adds than the general addition next to it) and the bucket flush at a change of key (its
+    # multiply-adds are address arithmetic): COLD.  Rule: a skipped range is cold iff it holds less than half of the multiply-adds of
+    # the smallest skipped range around it (or of the loop).
+    def n_mad(a, b):
+        return sum(1 for j in range(a, b) if instrs[j][0] == "v_mad_u64_u32")
+
+    spans = []
     for i in range(lo, hi):
         op, arg = instrs[i]
         if op.startswith("s_cbranch"):
             tgt = arg.split()[0].rstrip(",")
             if tgt in labels and i < labels[tgt] <= hi:
-                span = range(i + 1, labels[tgt])
-                n_mad = sum(1 for j in span if instrs[j][0] == "v_mad_u64_u32")
-                # a skipped span is "cold" when it is a whole alternative addition path, not the hot path guarded by `if (add_now)`
-                if 0 < n_mad and len(span) < 0.8 * (hi - lo) and _skips_are_rare(instrs, i):
-                    for j in span:
-                        cold[j] = True
+                a, b = i + 1, labels[tgt]
+                if n_mad(a, b):
+                    spans.append((a, b))
+    cold = [False] * len(instrs)
+    for a, b in spans:
+        parents = [(a2, b2) for a2, b2 in spans if a2 <= a and b <= b2 and (a2, b2) != (a, b)]
+        pa, pb = min(parents, key=lambda x: x[1] - x[0]) if parents else (lo, hi)
+        if 2 * n_mad(a, b) < n_mad(pa, pb):
+            for j in range(a, b):
+                cold[j] = True
     hot, cold_h, total = {}, {}, {}
     for i, (op, _) in enumerate(instrs):
         c = classify(op)
@@ -123,13 +134,6 @@ def loop_histogram(body):
             d = cold_h if cold[i] else hot
             d[c] = d.get(c, 0) + 1
     return hot, cold_h, total, (lo, hi, len(instrs))
-
-
-def _skips_are_rare(instrs, i):
-    """The branch over the same-x path is taken when a wave-wide OR of `same x` is zero: an s_cbranch_execz / scc0 right after an
-    s_and_saveexec or s_cmp on a ballot.  The `if (add_now)` guard of the hot path skips on execz as well; it is told apart by size in the
-    caller (it spans nearly the whole loop)."""
-    return True
 
 
 def report(law, as_json=False, extra_flags=()):
@@ -147,14 +151,14 @@ def report(law, as_json=False, extra_flags=()):
     print("    " + "  ".join("%s %d" % (k, hot[k]) for k, _ in CLASSES if k in hot))
     if cold:
         cv = sum(v for k, v in cold.items() if k not in ("lds", "vmem", "salu", "wait", "other"))
-        print("  cold blocks inside the loop (same-x branch):  VALU %d, MAD %d" % (cv, cold.get("mad", 0)))
+        print("  cold blocks inside the loop (same-x branch of the XYZZ laws, bucket flush):  VALU %d, MAD %d" % (cv, cold.get("mad", 0)))
     return out
 
 
 if __name__ == "__main__":
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     as_json = "--json" in sys.argv
-    laws = args or ["te29", "te28", "sw381", "g2p377"]
+    laws = args or ["te29", "te28", "sw381", "sw377", "g2p377", "g2p381"]
     outs = [report(l, as_json) for l in laws]
     if as_json:
         print(json.dumps(outs, indent=1))
