@@ -55,6 +55,9 @@ PMC_ROUND = "r05"
 STAGES = ("digits", "sort", "accumulate", "segreduce", "bucket_reduce", "total")
 
 
+MAD_PEAK = 1024 * 64 / 4.3 * 2.4e9   # lane-level v_mad_u64_u32 per second: 1024 SIMDs x 64 lanes / 4.3 cycles at the nominal 2.4 GHz (profiles/r01_ubench_valu_*.txt)
+
+
 def r_top(cid):
     return R381_TOP if cid in (1, 3) else R377_TOP
 
@@ -472,9 +475,15 @@ def measure_secondary_configs(E):
             sec[name] = {"ms_per_step": ms2, "value": n2 / ms2 * 1e3, "unit": "pairs/s", "window_bits": tm2["window_bits"],
                          "stage_ms": {k: tm2[k] for k in ("digits", "sort", "accumulate", "segreduce", "bucket_reduce", "host_fold")},
                          "roofline_frac_hbm": BYTES_PER_PAIR[cid2] * n2 / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+            g2p = c2.query("g2_paired") if cid2 >= 2 else 0
             if cid2 >= 2:
-                sec[name]["g2_paired"] = c2.query("g2_paired")   # bit mask of the kernels that run two lanes per point (csrc/fp2pair.hpp)
-            if cname == "bls12_377_g2":
+                sec[name]["g2_paired"] = g2p   # bit mask of the kernels that run two lanes per point (csrc/fp2pair.hpp)
+            # the integer roofline of this config's accumulation (as `roofline.integer` of the headline): multiply-adds per mixed addition are
+            # pinned on the ISA (tests/test_isa.py, tools/isa_histogram.py)
+            mads2 = {1: 3542, 2: 11480 if (g2p & 1) else 11088, 3: 11760 if (g2p & 1) else 11368}[cid2]
+            rate2 = mads2 * tm2["entries"] / (k_ms * 1e-3)
+            sec[name]["integer"] = {"mads_per_mixed_add": mads2, "lane_mads_per_s": rate2, "peak_lane_mads_per_s": MAD_PEAK, "frac": rate2 / MAD_PEAK}
+            if cname in ("bls12_377_g2", "bls12_381_g1"):
                 # BASELINE configs[4] once more with "precompute" = 2 (auto: tables from the free HBM, init untimed): non-default, reported beside
                 c2.close()
                 c2 = ea.MultiScalarMultContext(cname, device=E.local_rank)
@@ -916,7 +925,7 @@ def main():
         mads_per_add = {0: ((2359 if te_limb_bits == 29 else 2646) if ctx_te_path else 3416), 1: 3542, 2: 11480 if paired else 11088, 3: 11760 if paired else 11368}[cid]
         adds_per_launch = tm["entries"]          # one mixed addition per sorted entry (zero digits are a ~1e-6 fraction)
         mad_rate = mads_per_add * adds_per_launch / kern_s
-        mad_peak = 1024 * 64 / 4.3 * 2.4e9
+        mad_peak = MAD_PEAK
         ms_all = sorted(s["ms_per_step"] for s in samples)
         step_ms = elapsed / args.steps * 1e3
         at_ref = None
