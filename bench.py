@@ -51,7 +51,7 @@ BYTES_PER_PAIR = {0: 128.0, 1: 128.0, 2: 224.0, 3: 224.0}   # SURVEY.md section 
 R377_TOP = 0x12ab655e9a2ca556   # top 64-bit limb of the BLS12-377 scalar modulus (ARKC bls12_377/src/fields/fr.rs:24)
 R381_TOP = 0x73eda753299d7d48
 REF_CLOCK_GHZ = 1.95            # the clock the accumulate kernel ran at on the boxes of rounds 2-4 (profiles/r04_pmc_k_accumulate.json)
-PMC_ROUND = "r05"
+PMC_ROUND = "r06"
 STAGES = ("digits", "sort", "accumulate", "segreduce", "bucket_reduce", "total")
 
 

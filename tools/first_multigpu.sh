@@ -65,4 +65,6 @@ base = next((v[1] for k, v in rows.items() if v[0] == 1), None)
 for k, (n, v, ms, w) in rows.items():
     print("%-40s N=%d  %.3e pairs/s  %.1f ms/step  x%.2f  %s" % (k, n, v, ms, v / base if base else float("nan"), w))
 EOF
+# 5. measured against what the single-GPU numbers predict (profiles/r06_scale_model.json; tools/scale_model.py)
+python tools/scale_model.py --compare $OUT | tee $OUT/98_vs_model.txt
 [ -z "$FAILED" ] && echo "all steps passed" || echo "failed steps:$FAILED"
