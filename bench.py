@@ -507,7 +507,7 @@ def measure_secondary_configs(E):
 
 
 def measure_small_latency(E):
-    """Latency of small inputs (BASELINE.json configs[0] is 2^16; DESIGN.md section 5): wall ms of one MSM, median of 15, bases and
+    """Latency of small inputs (BASELINE.json configs[0] is 2^16; DESIGN.md section 8): wall ms of one MSM, median of 15, bases and
     scalars resident, with the device-side share."""
     torch, ea = E.torch, E.ea
     lat = {}
@@ -984,7 +984,7 @@ def main():
                          "integer": {"mads_per_mixed_add": mads_per_add, "lane_mads_per_s": mad_rate, "peak_lane_mads_per_s": mad_peak,
                                      "frac": mad_rate / mad_peak,
                                      "peak_is": "v_mad_u64_u32 issue limit at the nominal 2.4 GHz; the kernel runs power-limited near 1.9 GHz"},
-                         "note": "integer-VALU-bound path (no MFMA): the binding resource is VALU issue at the power-limited clock (DESIGN.md section 5)"},
+                         "note": "integer-VALU-bound path (no MFMA): the binding resource is VALU issue at the power-limited clock (DESIGN.md sections 2, 7)"},
         }
         if single and args.extras and cid < 2:
             # `value` above keeps the scalars in HBM (the brief's rule); these are the PCIe-inclusive figures, measured in this same run

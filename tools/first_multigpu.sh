@@ -1,6 +1,6 @@
 #!/bin/bash
 # The order to run things in on the FIRST box with >= 2 MI355X (no such box has been available to any round so far: the xGMI hop, RCCL
-# with more than one rank and the cross-device copies have never executed -- DESIGN.md section 6).  Every step says what a failure means
+# with more than one rank and the cross-device copies have never executed -- DESIGN.md section 9).  Every step says what a failure means
 # and which file to look at.  Run from the repository root:   bash tools/first_multigpu.sh [N]      (N = GPUs to use, default all)
 # Output: gpurun_out/first_multigpu/*.txt -- copy into profiles/ what you want kept.
 set -u
