@@ -51,9 +51,4 @@ hipError_t LaunchTe::reduce_scan_step(const XyzzDev* in, const XyzzDev* in2, Xyz
   return hipGetLastError();
 }
 
-hipError_t LaunchTe::bucket_merge(XyzzDev* total, const XyzzDev* part, uint32_t n, uint32_t* flags, hipStream_t st) {
-  hipLaunchKernelGGL((k_bucket_merge<G>), dim3(te_blocks(n)), dim3(256), 0, st, total, part, n, flags);
-  return hipGetLastError();
-}
-
 }  // namespace msm

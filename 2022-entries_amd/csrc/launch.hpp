@@ -65,7 +65,7 @@ struct LaunchTe {
                                   uint32_t windows, uint32_t out_stride, XyzzDev* out_a, XyzzDev* out_x, uint32_t* flags, hipStream_t st);
   static hipError_t reduce_scan_step(const XyzzDev* in, const XyzzDev* in2, XyzzDev* out, uint32_t nb, uint32_t windows, uint32_t d, uint32_t mode,
                                      uint32_t quad_limit, uint32_t* flags, hipStream_t st);
-  static hipError_t bucket_merge(XyzzDev* total, const XyzzDev* part, uint32_t n, uint32_t* flags, hipStream_t st);
+  // (no bucket_merge: the later chunks of a carried batch accumulate straight onto the stored buckets -- SegOutT::carry_in)
 };
 
 // Bucket grouping (partition.hip): digits + MSD partition of the (key, value) entries.  scalar_field: 0 = BLS12-377 Fr, 1 = BLS12-381 Fr

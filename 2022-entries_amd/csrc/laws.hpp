@@ -55,6 +55,7 @@ struct SwLaw {
   using BaseDev = AffineDevT<T>;
   static constexpr int LANES = 1;
   static constexpr bool CHECKS = false;
+  static constexpr bool CARRY_IN = false;   // carried batches merge their chunks' buckets in a pass of their own (msm_kernels.hpp, carry_begin_run)
   static constexpr int ACC_WAVES = E::ACC_WAVES;
   static constexpr bool PREFETCH_BASE = E::PREFETCH_BASE;
   static constexpr int GATHER_SECTORS = sizeof(AffineDevT<T>) / 64;   // 64-B sectors of a record that hold data
@@ -96,6 +97,7 @@ struct TeLaw {
   using BaseDev = TeAffineDev;
   static constexpr int LANES = 1;
   static constexpr bool CHECKS = true;
+  static constexpr bool CARRY_IN = true;    // later chunks of a carried batch accumulate straight onto the stored buckets
 #ifndef TE_ACC_WAVES
 #define TE_ACC_WAVES 2
 #endif
@@ -174,6 +176,7 @@ struct SwPairLaw {
   using BaseDev = AffineDevT<Fe2>;
   static constexpr int LANES = 2;
   static constexpr bool CHECKS = false;
+  static constexpr bool CARRY_IN = false;
 #ifndef MSM_G2P_ACC_WAVES
 #define MSM_G2P_ACC_WAVES 2
 #endif

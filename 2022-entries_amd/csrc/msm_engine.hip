@@ -566,7 +566,7 @@ void release_work_buffers(mi355_msm_ctx* ctx, bool keep_carry = false) {
   size_t nb = 0;
   DevBuf* const* wb = work_buffers(ctx, nb);
   for (size_t i = 0; i < nb; i++)
-    if (!(keep_carry && wb[i] == &ctx->carry_buckets)) wb[i]->release();
+    if (!(keep_carry && (wb[i] == &ctx->carry_buckets || wb[i] == &ctx->buckets))) wb[i]->release();   // (XYZZ batches total in carry_buckets, Edwards batches in buckets)
 }
 
 // Everything the context holds in device memory (the stateless pool's size bound, msm_stateless.hpp).
@@ -1024,10 +1024,14 @@ bool run_chunk_impl(mi355_msm_ctx* ctx, const uint32_t* d_scalars, size_t base0,
   HIP_OK(gerr);
   const uint2* entries = gb.entries[sorted];
   const uint32_t* n_real = gb.totals;
-  HIP_OK(hipMemsetAsync(ctx->buckets.p, 0, nbuckets * sizeof(XyzzDev), st));
+  // Carried batches: the twisted-Edwards kernels accumulate a later chunk straight onto the buckets the earlier chunks left
+  // (SegOutT::carry_in); the XYZZ kernels fill a fresh array that k_bucket_merge adds to the batch's (see carry_begin_run for why).
+  const bool carry_in = TE && carry && !carry->first;
+  if (!carry_in) HIP_OK(hipMemsetAsync(ctx->buckets.p, 0, nbuckets * sizeof(XyzzDev), st));
   HIP_OK(hipEventRecord(ev[2], st));
 
   SegOut so{ctx->buckets.as<XyzzDev>(), ctx->slots[0].as<XyzzDev>(), ctx->slot_keys[0].as<uint32_t>()};
+  so.carry_in = carry_in ? 1u : 0u;
   if constexpr (TE)
     HIP_OK(LaunchTe::accumulate(entries, n_real, p.K, ctx->te_bases.as<TeAffineDev>(), so, p.nlanes, flags, st));
   else
@@ -1060,18 +1064,18 @@ bool run_chunk_impl(mi355_msm_ctx* ctx, const uint32_t* d_scalars, size_t base0,
       cur ^= 1;
     }
   }
-  // carried buckets: the first chunk's array becomes the batch's, later chunks are added to it
+  // carried buckets
   XyzzDev* bucket_src = ctx->buckets.as<XyzzDev>();
-  if (carry) {
-    if (carry->first) {
-      std::swap(ctx->buckets, ctx->carry_buckets);
-    } else {
-      if constexpr (TE)
-        HIP_OK(LaunchTe::bucket_merge(ctx->carry_buckets.as<XyzzDev>(), ctx->buckets.as<XyzzDev>(), (uint32_t)nbuckets, flags, st));
-      else
+  if constexpr (!TE) {
+    // XYZZ: the first chunk's array becomes the batch's, later chunks are added to it
+    if (carry) {
+      if (carry->first) {
+        std::swap(ctx->buckets, ctx->carry_buckets);
+      } else {
         HIP_OK(Launch<E>::bucket_merge(ctx->carry_buckets.as<XyzzDev>(), ctx->buckets.as<XyzzDev>(), (uint32_t)nbuckets, st, (ctx->opt_g2_paired & 16) != 0));
+      }
+      bucket_src = ctx->carry_buckets.as<XyzzDev>();
     }
-    bucket_src = ctx->carry_buckets.as<XyzzDev>();
   }
   HIP_OK(hipEventRecord(ev[4], st));
   ctx->last_info[0] = p.c;
@@ -1283,7 +1287,10 @@ void run_device_t(mi355_msm_ctx* ctx, uint8_t* out, const uint32_t* d_scalars, s
   size_t max_chunk = ctx->opt_max_chunk ? (size_t)ctx->opt_max_chunk : ((size_t)1 << 26);
   ctx->chunk_cap = 0;
   const size_t out_bytes = 3 * 4 * E::WORDS;
-  const size_t div = ctx->opt_first_piece_div ? (size_t)ctx->opt_first_piece_div : (ctx->opt_carry ? 13 : 4);
+  // first piece of a host-scalar batch = 1/div of it.  Carried, with a merge pass per piece (XYZZ): 13 (1/13 + 3/13 + 9/13); carried onto
+  // the stored buckets (twisted Edwards, round 6: a piece costs no merge): 26, a fourth piece and half the PCIe wait before the first
+  // kernel (2^26: 112.1 -> 110.2 ms same-box, profiles/r06_ab_carry_in.txt); not carried: 4
+  const size_t div = ctx->opt_first_piece_div ? (size_t)ctx->opt_first_piece_div : (ctx->opt_carry ? (ctx->te_active ? 26 : 13) : 4);
   const std::vector<size_t> pb = (hb && batches) ? msm_host::first_batch_pieces(n, max_chunk, div) : std::vector<size_t>{0, n};
   const size_t P = pb.size() - 1;   // pieces of batch 0
   size_t issued = 0;                // ... whose copy has been issued

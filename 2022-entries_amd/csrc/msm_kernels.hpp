@@ -87,6 +87,22 @@ __device__ __forceinline__ void seg_flush(const SegOutT<typename G::MemT>& o, ui
   }
 }
 
+// Carried buckets WITHOUT a merge pass (SegOutT::carry_in; laws with G::CARRY_IN, i.e. the twisted-Edwards kernels).  A batch that runs
+// as several chunks keeps ONE bucket array.  The run that starts bucket `key` in this chunk -- any run but a lane's first, and a lane's
+// first run unless the entry before the lane has the same key (then the run started in an earlier lane, and THAT fragment took the
+// stored value) -- begins from the value the earlier chunks left; the fragments of a bucket still add up to one sum (k_segreduce),
+// which now includes it, and a bucket this chunk never touches keeps its value.  One 224-B read per run (~64 additions) instead of a
+// pass over every bucket per chunk (k_bucket_merge: one full addition + 3 x 224 B per bucket and chunk, and a second bucket array).
+// The XYZZ kernels keep the merge pass: a global load into the accumulator inside their loop costs them 65 VGPRs -- a wave per SIMD
+// (165 -> 230; the two-lane G2 kernel spills) -- whatever its form (profiles/r06_ab_carry_in.txt).
+template <class G>
+__device__ __forceinline__ void carry_begin_run(const SegOutT<typename G::MemT>& o, uint32_t key, XyzzT<typename G::T>& acc, bool& fresh, uint32_t half) {
+  // (straight into the accumulator, which is dead here: the previous run has been flushed)
+  acc = G::load_pt(o.buckets + key, half);
+  fresh = G::nothing(acc);        // an empty bucket: the run starts as it would without carrying
+  if (fresh) G::begin_run(acc);
+}
+
 // The hot kernel.  Lane t walks sorted entries [t*K, (t+1)*K): ~K mixed adds, one bucket store per run.
 // The next base is fetched before the current add so the gather latency hides under ~5k VALU ops.
 // G = the group-law policy (laws.hpp); `flags[1]` is raised when the law reports a result it could not compute.
@@ -332,6 +348,7 @@ __global__ void __launch_bounds__(256, G::ACC_WAVES) k_accumulate_glds(const uin
 #endif
     if (add_now) {
       if (key != cur) {
+        const bool lane_first = cur == KEY_NONE;
         if (cur != KEY_NONE) {
           seg_flush<G>(out, t, nlanes, cur, acc, first, false, half);
           first = false;
@@ -339,6 +356,10 @@ __global__ void __launch_bounds__(256, G::ACC_WAVES) k_accumulate_glds(const uin
         cur = key;
         fresh = true;
         G::begin_run(acc);
+        if constexpr (G::CARRY_IN) {
+          // (rare: once per run, and only in the later chunks of a carried batch; the entry before the lane is read here, not kept in a register)
+          if (out.carry_in && !(lane_first && t > 0 && entries[beg - 1].y == key)) carry_begin_run<G>(out, key, acc, fresh, half);
+        }
       }
 #if MSM_ACC_PRIO == 1
       __builtin_amdgcn_s_setprio(2);

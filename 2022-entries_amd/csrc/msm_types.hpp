@@ -27,6 +27,9 @@ struct SegOutT {
   XyzzDevT<T>* buckets;
   XyzzDevT<T>* slots;   // 2 per lane: [2t] head, [2t+1] tail
   uint32_t* slot_keys;  // KEY_NONE = empty slot
+  // 1: the buckets already hold the sums of the batch's earlier chunks (carried buckets): the run that STARTS a bucket in this chunk
+  // begins from the stored value instead of the identity, so the chunk's sums land on top of it with no merge pass
+  uint32_t carry_in = 0;
 };
 using SegOut = SegOutT<Fe>;
 

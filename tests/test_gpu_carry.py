@@ -1,6 +1,6 @@
 """GPU: carried buckets.  A batch that runs as several chunks (max_chunk, a memory budget, the first piece of a host-scalar batch,
 the slices of the stateless call) keeps ONE bucket array: every chunk accumulates with the window size of the whole batch, chunk 0's
-buckets become the batch's, later chunks are added to them (k_bucket_merge) and only the last chunk reduces.  The reference's
+buckets become the batch's, later chunks are added to them (k_bucket_merge; the twisted-Edwards kernels since round 6 accumulate straight onto the stored buckets instead: SegOutT::carry_in) and only the last chunk reduces.  The reference's
 counterpart is the single bucket set its batches of points feed (CMB MSM.cu:437-505 accumulates all its point groups before
 ReduceBuckets runs once).  Results are bit-exact against the CPU oracle and against the per-chunk-reduce path (option carry = 0)."""
 import random
@@ -155,7 +155,9 @@ def test_host_scalar_batches_split_their_first_piece(ea, cid):
     ref = ctx.run(torch.from_numpy(sc).cuda())
     assert ctx.last_timings()["launches"] == 2
     # (first piece 1/div of the batch, every further piece three times its predecessor: 13 -> 1/13 + 3/13 + 9/13)
-    for div, carry, pieces in ((0, 1, 3), (4, 1, 2), (40, 1, 4), (0, 0, 2), (16, 0, 3)):
+    # default divisor: 13 with a merge pass per piece (XYZZ), 26 when the pieces accumulate onto the stored buckets (the Edwards kernels of
+    # BLS12-377 G1: 1/26 + 3/26 + 9/26 + the rest)
+    for div, carry, pieces in ((0, 1, 4 if cid == 0 else 3), (13, 1, 3), (4, 1, 2), (40, 1, 4), (0, 0, 2), (16, 0, 3)):
         ctx.set_option("first_piece_div", div)
         ctx.set_option("carry", carry)
         assert ctx.run(sc) == ref, (div, carry)

@@ -80,16 +80,19 @@ def test_accumulate_kernel_isa(law):
         valu = [o for o in ops if o.startswith("v_")]
         # whole kernel (static count), prologue, flushes and the queue rotation (14 moves) included.  13 x 29: two carry passes per
         # addition (te_tail: F and H) are part of it -- 3107 VALU per trip against 3348 (tools/isa_histogram.py)
-        assert len(valu) - mads <= (1050 if law == "te" else 1000), len(valu) - mads
+        # + ~140 in the cold block of carried batches (SegOutT::carry_in, msm_kernels.hpp carry_begin_run: a run of a later chunk starts from
+        # the stored bucket), outside the per-addition path -- tools/isa_histogram.py te29 separates the two: 3107 per trip, 223 cold
+        assert len(valu) - mads <= 1200, len(valu) - mads
         if law == "te":
-            assert len(valu) <= 3500, len(valu)
+            assert len(valu) <= 3650, len(valu)
     else:
         # the common path of the mixed addition keeps neither base coordinate alive (curve.hpp xyzz_madd_common): 3 waves/SIMD
         assert res["vgprs"] <= 168, res["vgprs"]
     # selects are emitted in the VOP3 form: back-to-back v_cndmask_b32_e32 (mask implicit in VCC) issue at 22.9 cycles in isolation
     # against 4.2 for v_cndmask_b32_e64 (profiles/r02_ubench_valu_w4.txt).  In this kernel the difference did not show
     # (profiles/r02_ab_cndmask.txt); the form is pinned anyway so that a scheduling change cannot bring the slow case back
-    assert ops.count("v_cndmask_b32_e32") <= 2, ops.count("v_cndmask_b32_e32")
+    # (static count of the whole kernel: the cold carry-in block of the Edwards kernel holds one more)
+    assert ops.count("v_cndmask_b32_e32") <= 3, ops.count("v_cndmask_b32_e32")
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
