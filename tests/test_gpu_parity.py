@@ -652,13 +652,13 @@ def test_full_size_properties(ea, oracle, torch_cuda, cid, curve, npow):
         ctx_pre.set_bases(bases)
         assert ctx_pre.run(as_bytes(k1))[0] == r1
         ctx_pre.close()
-    # (8) the harness's hand-over: scalars in HOST memory, two batches -- the first batch's copy is split 1/13 + 3/13 + 9/13 and
-    #     computed as three chunks over one carried bucket array (CMB MSM.cu:419-434 splits 1/4 + 3/4), the second is copied while
-    #     the first computes
+    # (8) the harness's hand-over: scalars in HOST memory, two batches -- the first batch's copy is split 1/26 + 3/26 + 9/26 + the rest
+    #     (the Edwards kernels accumulate every piece onto ONE bucket array; CMB MSM.cu:419-434 splits 1/4 + 3/4), the second batch is
+    #     copied while the first computes
     if npow >= 23 and cid == 0:
         host = torch.cat([as_bytes(k1), as_bytes(k2)]).cpu().numpy()
         assert ctx.run(host) == [r1, r2]
-        assert ctx.last_timings()["launches"] == 4          # 3 chunks for batch 0, 1 for batch 1
+        assert ctx.last_timings()["launches"] == 5          # 4 chunks for batch 0, 1 for batch 1
     # (9) BLS12-377: the twisted-Edwards path (default) and the XYZZ path agree at full size
     if cid == 0:
         assert ctx.query("twisted_edwards") == 1 and ctx.query("twisted_edwards_fallbacks") == 0
