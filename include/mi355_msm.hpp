@@ -76,6 +76,40 @@ inline std::vector<G1Projective> multi_scalar_mult(MultiScalarMultContext& ctx, 
   return ret;
 }
 
+// Stream-ordered run (mi355_msm_run_async; the role of ML bellman-cuda.h:48-75 msm_execute_async as P1A matter-labs/src/lib.rs:150-190
+// uses it): `d_scalars` -- DEVICE memory, batch_size * npoints BigInteger256 -- must stay valid until wait() returns; the MSM is ordered
+// after the work already enqueued in `stream` and runs on the context's own stream.  The job owns its output buffer.
+struct MsmJob {
+  mi355_msm_job* job = nullptr;
+  std::vector<G1Projective> out;
+  MsmJob() = default;
+  MsmJob(const MsmJob&) = delete;
+  MsmJob& operator=(const MsmJob&) = delete;
+  MsmJob(MsmJob&& o) noexcept : job(o.job), out(std::move(o.out)) { o.job = nullptr; }
+  bool done() const { return job == nullptr || mi355_msm_job_done(job) != 0; }
+  std::vector<G1Projective>& wait() {
+    if (job) {
+      mi355_msm_job* j = job;
+      job = nullptr;
+      check(mi355_msm_job_wait(j));   // (releases the handle, whatever the status)
+    }
+    return out;
+  }
+  ~MsmJob() {
+    if (job) {
+      RustError e = mi355_msm_job_wait(job);
+      if (e.message) std::free(e.message);
+    }
+  }
+};
+
+inline MsmJob multi_scalar_mult_async(MultiScalarMultContext& ctx, const void* d_scalars, size_t batch_size, void* stream = nullptr) {
+  MsmJob j;
+  j.out.resize(batch_size);
+  check(mi355_msm_run_async(ctx.context, j.out.data(), d_scalars, ctx.npoints, batch_size, stream, nullptr, nullptr, &j.job));
+  return j;
+}
+
 // VariableBaseMSM::msm_bigint shape: one stateless MSM, chopped to the shorter input.
 inline G1Projective msm(const std::vector<G1Affine>& bases, const std::vector<BigInteger256>& scalars, int curve = MI355_BLS12_377_G1) {
   const size_t n = bases.size() < scalars.size() ? bases.size() : scalars.size();

@@ -74,6 +74,36 @@ int main(int argc, char** argv) {
   mi355::G1Projective one = mi355::msm(points, few, CURVE), exp1;
   oracle_msm(CURVE, points.data(), sizeof(mi355::G1Affine), few.data(), 10, &exp1, 0);
   if (memcmp(&one, &exp1, sizeof one) != 0) bad++;
+  // (4) the stream-ordered run (mi355::multi_scalar_mult_async): scalars in DEVICE memory, the call returns at once, wait() gives the same
+  //     points.  This harness is plain g++ (no HIP headers), so the three runtime calls it needs come from the HIP library by name.
+  {
+    void* hip = dlopen("libamdhip64.so", RTLD_NOW | RTLD_GLOBAL);
+    typedef int (*malloc_t)(void**, size_t);
+    typedef int (*memcpy_t)(void*, const void*, size_t, int);
+    typedef int (*free_t)(void*);
+    malloc_t hip_malloc = hip ? (malloc_t)dlsym(hip, "hipMalloc") : nullptr;
+    memcpy_t hip_memcpy = hip ? (memcpy_t)dlsym(hip, "hipMemcpy") : nullptr;
+    free_t hip_free = hip ? (free_t)dlsym(hip, "hipFree") : nullptr;
+    if (!hip_malloc || !hip_memcpy || !hip_free) {
+      fprintf(stderr, "libamdhip64.so: hipMalloc / hipMemcpy / hipFree not found\n");
+      bad++;
+    } else {
+      void* d_scalars = nullptr;
+      const size_t bytes = scalars.size() * sizeof(mi355::BigInteger256);
+      if (hip_malloc(&d_scalars, bytes) != 0 || hip_memcpy(d_scalars, scalars.data(), bytes, 1 /* hipMemcpyHostToDevice */) != 0) {
+        fprintf(stderr, "device allocation / copy failed\n");
+        bad++;
+      } else {
+        mi355::MsmJob job = mi355::multi_scalar_mult_async(ctx, d_scalars, batches);
+        std::vector<mi355::G1Projective>& got3 = job.wait();
+        if (!job.done() || got3.size() != batches || memcmp(got3.data(), got.data(), batches * sizeof(mi355::G1Projective)) != 0) {
+          fprintf(stderr, "the asynchronous run differs from the synchronous one\n");
+          bad++;
+        }
+      }
+      if (d_scalars) hip_free(d_scalars);
+    }
+  }
   printf("msm_correctness curve=%d npoints=2^%s batches=%zu: %s\n", CURVE, argv[2], batches, bad ? "FAILED" : "ok");
   return bad ? 1 : 0;
 }
