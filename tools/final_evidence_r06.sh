@@ -23,7 +23,10 @@ if [[ " $PARTS " == *" prof "* ]]; then
   find gpurun_out -name "*.csv" -size +2M -delete
 fi
 if [[ " $PARTS " == *" tests "* ]]; then
-  python -m pytest tests -m gpu -q 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl" | tail -6 > gpurun_out/${R}_pytest_gpu.txt
+  python -m pytest tests -m gpu -q 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl" > gpurun_out/${R}_pytest_gpu_full.txt
+  # (the whole report when something failed, the summary otherwise)
+  if grep -q "failed" gpurun_out/${R}_pytest_gpu_full.txt; then tail -120 gpurun_out/${R}_pytest_gpu_full.txt > gpurun_out/${R}_pytest_gpu.txt; else tail -6 gpurun_out/${R}_pytest_gpu_full.txt > gpurun_out/${R}_pytest_gpu.txt; fi
+  rm -f gpurun_out/${R}_pytest_gpu_full.txt
 fi
 if [[ " $PARTS " == *" bench "* ]]; then
   python bench.py > gpurun_out/${R}_bench.json 2> gpurun_out/${R}_bench.err
