@@ -93,7 +93,10 @@ def test_async_call_returns_at_once_and_other_streams_overlap(ea):
     jobs = [ctx.run_async(scalars) for _ in range(3)]
     assert ctx.query("async_pending") >= 1
     assert all(j.wait()[0] == ref for j in jobs)
+    # destroying a context with jobs pending runs them to completion first; their handles stay valid
+    jobs = [ctx.run_async(scalars) for _ in range(2)]
     ctx.close()
+    assert all(j.done() for j in jobs) and all(j.wait()[0] == ref for j in jobs)
 
 
 def test_async_callback_and_errors_through_the_c_abi(ea):
