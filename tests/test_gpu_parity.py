@@ -518,6 +518,33 @@ def test_g2_reference_generator_has_order_r_on_the_gpu(ea, golden_constants, tor
 
 
 @pytest.mark.parametrize("cid,c,rid", G2_CURVES)
+def test_g2_cofactor_known_answers_on_the_gpu(ea, golden_constants, torch_cuda, cid, c, rid):
+    """The reference's G2 cofactor literals through the HIP path (GPU twin of tests/test_oracle.py::test_g2_cofactor_known_answers):
+    COFACTOR_INV * (COFACTOR * G2) is the literal generator again, and COFACTOR * Q for a point Q of E'(Fq2) OFF the order-r subgroup
+    (solved from the curve equation) is killed by r.  ARKC bls12_377/src/curves/g2.rs:17-34, bls12_381/src/curves/g2.rs:22-40."""
+    from test_oracle import _cofactor_chunks, _g2_point_off_the_subgroup
+
+    k = golden_constants[c.name]
+    h, hinv = int(k["COFACTOR"]), int(k["COFACTOR_INV"])
+    G = c.generator()
+    pts, sc = _cofactor_chunks(c, G, h)
+    hG = c.mul(h, G)
+    assert ea.msm(c.encode_affine_array(pts), m.encode_scalars(sc), c.name) == c.encode_projective_normalized(hG)
+    assert ea.msm(c.encode_affine_array([hG]), m.encode_scalars([hinv]), c.name) == c.encode_projective_normalized(G)
+    Q = _g2_point_off_the_subgroup(c, 1000)
+    pts, sc = _cofactor_chunks(c, Q, h)
+    hQ = c.mul(h, Q)
+    assert ea.msm(c.encode_affine_array(pts), m.encode_scalars(sc), c.name) == c.encode_projective_normalized(hQ)
+    assert ea.msm(c.encode_affine_array([hQ]), m.encode_scalars([c.r]), c.name) == c.encode_projective_normalized(None)
+    # the same pairs many times over on one context (the throughput kernels, two lanes per point): 512 copies of the chunk set
+    reps = 512
+    ctx = ea.multi_scalar_mult_init(c.encode_affine_array(pts) * reps, c.name)
+    got = ea.multi_scalar_mult(ctx, None, m.encode_scalars(sc) * reps)[0]
+    ctx.close()
+    assert got == c.encode_projective_normalized(c.mul(reps, hQ))
+
+
+@pytest.mark.parametrize("cid,c,rid", G2_CURVES)
 def test_g2_edge_cases_and_stateless(ea, oracle, torch_cuda, cid, c, rid):
     rng = random.Random(77)
     for n in (0, 1, 2, 31, 33, 300):
