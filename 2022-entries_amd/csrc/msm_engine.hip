@@ -216,6 +216,43 @@ struct DevBuf {
 inline uint32_t ceil_div(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
 inline uint32_t ilog2_floor(uint64_t v) { uint32_t r = 0; while (v >>= 1) r++; return r; }
 
+// ---- the anchored window (round 6) ------------------------------------------------------------------------------------------
+// Signed digits carry: the window above the last FULL window of a canonical scalar holds `rem` = scalar_bits mod c bits plus the
+// carry of the one below, so with rem <= 1 -- BLS12-377's Fr: 253 = 11 x 23, 252 = 12 x 21 = 14 x 18 -- it has (almost) no bits of its
+// own and is non-zero all the same: for 57 % of the scalars at c = 21 (14 % would be the bit's own share), 14 % at c = 23.  The ZPrize
+// winners remove those additions by halving the scalar (k -> r - k, -P: CMB ProcessSignedDigits.cu:10-20; option assume_subgroup here),
+// which is only true when r P = O.
+// Without any assumption: END the carry chain at the last full window -- its value v in [0, 2^c] is written 2^(c-1) + s,
+// |s| <= 2^(c-1), the same buckets -- and add the constant part, 2^(c a + c - 1) x (the plain sum of the bases of the run), once on
+// the host.  That sum depends on the bases only: computed by the pipeline itself (all scalars 1) the first time a context runs a
+// given number of pairs and kept (AnchorSums).  A scalar of zero then costs ONE addition (its digit in the anchored window is
+// -2^(c-1)) instead of none -- the price; contexts whose bases change with every call (the stateless pipeline) do not use it.
+// Measured (profiles/r06_ab_anchor.txt): BLS12-377 G1 2^26, c = 21 anchored against c = 20 plain: -1.0 %; with tables (c = 23) 2^24: -2.5 %,
+// G2 2^24: -1.2 % -- what signed-digit Pippenger has left once the limb shape is settled.
+constexpr uint32_t kNoAnchor = 0xffffffffu;
+// Windows' worth of additions per canonical, uniformly drawn scalar: `full` = scalar_bits / c whole windows and what lies above them.
+// With q = 2^(bits-1) / r = 0.857 (BLS12-377), 0.552 (BLS12-381) -- the share of the scalars whose top bit is clear:
+//   plain signed digits, rem = 0: the window above takes the carry of the top window, whose value stays below 2^c r / 2^bits: 1 - q;
+//                        rem >= 1: it holds rem bits and a carry that comes half of the time: 1 - q 2^(1-rem) / 2
+//   anchored: no carry arrives; the rem bits alone: 1 - q 2^(1-rem) (rem = 0: nothing is left above)
+void eff_windows(int scalar_bits, int c, double& plain, double& anchored) {
+  const int full = scalar_bits / c, rem = scalar_bits - full * c;
+  const double q = scalar_bits == 253 ? 0.857 : 0.552;
+  const double top_clear = rem == 0 ? 1.0 : std::min(1.0, q * std::ldexp(1.0, 1 - rem));   // P(the rem bits above the full windows are all zero)
+  plain = full + (rem == 0 ? 1.0 - q : 1.0 - 0.5 * top_clear);
+  anchored = full + (1.0 - top_clear);
+}
+// the window to anchor for window size c: the last full one, where that saves at least 1 % of the additions -- BLS12-377: c = 23 (1.3 %),
+// 21 (3.4 %), 18 (2.9 %), 14, 12, ...; BLS12-381: c = 17 (2.9 %), 15.  (`always`: option anchor = 2 -- whatever the window size, for tests:
+// the recoding is exact for any c)
+uint32_t anchor_window(int c, int scalar_bits, bool always = false) {
+  const int full = scalar_bits / c;
+  if (full < 1) return kNoAnchor;
+  double plain, anchored;
+  eff_windows(scalar_bits, c, plain, anchored);
+  return (always || (plain - anchored) >= 0.01 * plain) ? (uint32_t)(full - 1) : kNoAnchor;
+}
+
 // Window size.  Cost model in field-multiply units: one mixed add (10) per non-zero digit, ~50 per bucket for the
 // bucket->window reduction (measured: 0.79 ns/bucket vs 0.15 ns/add).  Canonical scalars have `scalar_bits` bits, so the
 // top window is only partly populated: with `rem` significant bits left it behaves like a full window, with none it
@@ -223,7 +260,8 @@ inline uint32_t ilog2_floor(uint64_t v) { uint32_t r = 0; while (v >>= 1) r++; r
 // scalar is legal), or for ONE window when precomputed tables let all digits share a bucket set.
 // `levels` = precomputed table levels k (0: none; >= windows: one bucket set for all): windows g, g + G, ... share bucket set g,
 // G = ceil(windows / k) sets exist.
-int choose_window_bits(size_t n, int scalar_bits, bool shared_buckets, bool fold = false, int levels = 0) {
+// `anchor_min_c` (0: plain digits): window sizes from this one on are priced with their anchored window, where they have one.
+int choose_window_bits(size_t n, int scalar_bits, bool shared_buckets, bool fold = false, int levels = 0, int anchor_min_c = 0) {
   // Between 2^12 and 2^19 pairs an MSM is latency, not throughput: what a window size costs is the launches it implies
   // (two scan steps of the bucket reduction per bit, a grouping pass more from 12 bits on, per-window steps of the level-1
   // tiles) and the model below does not see them.  Measured on all three curves (tools/small_c_sweep.py,
@@ -251,7 +289,13 @@ int choose_window_bits(size_t n, int scalar_bits, bool shared_buckets, bool fold
     //  margin is inside its error: G2 2^24 chose c = 18 and lost 4 %, profiles/r03_ab_fold.txt)
     const int bits = (fold && n >= ((size_t)1 << 25)) ? scalar_bits - 1 : scalar_bits;
     const int full = bits / c, rem = bits - full * c;
-    const double eff = full + (rem >= 2 ? 1.0 : (bits != scalar_bits && rem == 0 ? (scalar_bits == 253 ? 0.145 : 0.448) : 0.55));
+    double eff = full + (rem >= 2 ? 1.0 : (bits != scalar_bits && rem == 0 ? (scalar_bits == 253 ? 0.145 : 0.448) : 0.55));
+    // (a window size chosen WITHOUT this term is still anchored where it can be: that is free.  Where the term may MOVE the choice is
+    //  decided by measurement, Plan::plan: profiles/r06_ab_anchor.txt)
+    if (anchor_min_c > 0 && !fold && c >= anchor_min_c && anchor_window(c, scalar_bits) != kNoAnchor) {
+      double plain;
+      eff_windows(scalar_bits, c, plain, eff);
+    }
     const int wins = (257 + c - 1) / c;
     const double alloc = shared_buckets ? (double)(levels > 0 ? (wins + std::min(levels, wins) - 1) / std::min(levels, wins) : 1) : (double)wins;
     // from 22 bits on the grouping needs a second generic pass (level 1 resolves 10 bucket bits, a pass 10 more): +5.5 ms against 95 ms of
@@ -282,6 +326,7 @@ struct Plan {
   uint32_t c, windows, half, keybits;
   uint32_t bucket_windows;  // windows that own buckets: `windows`; with precomputed tables the bucket sets G = ceil(windows / levels)
   uint32_t levels;          // table levels in use (1 = none)
+  uint32_t anchor;          // the anchored window (kNoAnchor: plain signed digits)
   uint64_t entries;     // windows * n
   uint32_t K, nlanes;   // accumulate geometry
   uint32_t segK;        // fragment-merge fan-in
@@ -325,6 +370,17 @@ struct mi355_msm_ctx {
   long opt_precompute = 0;
   long opt_table_levels = 0;      // with precompute: table levels k (0 = one per window); windows g, g + G, ... share bucket set g
   long opt_assume_subgroup = 0;   // 1: every base is in the order-r subgroup (r P = O), so a scalar k in (r/2, r) may run as (r - k)(-P)
+  long opt_anchor = 1;            // option "anchor_window": 1 = end the signed-digit carry chain at the last full window where that saves additions
+  bool anchor_armed = false;      // ... for the run under way: the sum of its bases is at hand (run_device_t)
+  struct AnchorSum {
+    size_t n;                     // bases [0, n)
+    int shift;                    // -1: their plain sum; >= 0: 2^shift times it
+    std::vector<uint8_t> pt;      // a HostTail<E>::Pt
+  };
+  std::vector<AnchorSum> anchor_sums;   // of the current base set (set_bases clears it); a handful of entries
+  uint64_t anchor_sums_computed = 0;
+  float anchor_sum_ms = 0;        // host wall time the most recent run spent computing such a sum (0: it was at hand)
+  uint32_t last_anchor = kNoAnchor;   // the anchored window of the most recent chunk
   long opt_reduce_log_chunk = 0, opt_reduce_log_chunk0 = 0;
   long opt_reduce_scan = -1;      // 0: recursive chunked running sums only; otherwise the scan tail (default)
   long opt_reduce_fill = 0;       // waves per SIMD the first chunked level of the bucket reduction is cut for (0 = the default, 1)
@@ -366,6 +422,16 @@ struct mi355_msm_ctx {
   uint64_t last_info[8] = {};
 
   int scalar_bits() const { return (curve == MI355_BLS12_381_G1 || curve == MI355_BLS12_381_G2) ? 255 : 253; }
+  // the anchored window is a throughput device: batches of 2^20 pairs and more, carried buckets (one window size per batch), no halved scalars
+  // Window sizes the model may move to BECAUSE they have an anchored window (tools/calibrate_window_model.py with the option on,
+  // profiles/r06_ab_anchor.txt).  BLS12-377: from c = 21 -- 2^26 pairs run at 21 instead of 20 (-1.0 %); below, c = 18 anchored loses
+  // to its plain neighbours although it has fewer additions (2^23: 16.65 ms against 15.99 at c = 17; 2^24: 30.78 against 28.97 at c = 20).
+  // BLS12-381 G1: any -- c = 17 (255 = 15 x 17) wins at 2^22 (11.26 ms against 12.06 at c = 16) and 2^23 (20.10 against 20.85 at c = 18).
+  // BLS12-381 G2: not measured, left alone (no window size >= 21 has an anchored window there).
+  int anchor_min_c() const { return curve == MI355_BLS12_381_G1 ? 2 : 21; }
+  bool anchor_wanted(size_t n_batch) const {
+    return opt_anchor != 0 && opt_carry != 0 && opt_assume_subgroup == 0 && n_batch >= (opt_anchor == 2 ? (size_t)1 : (size_t)1 << 20);
+  }
 
   // use_tables = false plans the run WITHOUT the precomputed tables of this context (the XYZZ fallback of a
   // twisted-Edwards context, whose short-Weierstrass tables were dropped)
@@ -378,7 +444,9 @@ struct mi355_msm_ctx {
     else if (force_c)
       p.c = force_c;
     else
-      p.c = (opt_window_bits && !pre_c) ? (uint32_t)opt_window_bits : (uint32_t)choose_window_bits(n, scalar_bits(), false, opt_assume_subgroup != 0);
+      p.c = (opt_window_bits && !pre_c) ? (uint32_t)opt_window_bits
+                                        : (uint32_t)choose_window_bits(n, scalar_bits(), false, opt_assume_subgroup != 0, 0, anchor_wanted(n) ? anchor_min_c() : 0);
+    p.anchor = anchor_armed ? anchor_window((int)p.c, scalar_bits(), opt_anchor == 2) : kNoAnchor;
     p.windows = (257 + p.c - 1) / p.c;
     p.levels = tables ? std::min<uint32_t>(pre_windows, p.windows) : 1;
     p.bucket_windows = ceil_div(p.windows, p.levels);
@@ -744,6 +812,8 @@ int precompute_auto_levels(mi355_msm_ctx* ctx, size_t n) {
     tmp.pre_windows = ts.levels;
     tmp.opt_window_bits = ctx->opt_window_bits;
     tmp.opt_assume_subgroup = ctx->opt_assume_subgroup;
+    tmp.opt_anchor = ctx->opt_anchor;
+    tmp.opt_carry = ctx->opt_carry;
     tmp.opt_lane_entries = ctx->opt_lane_entries;
     tmp.opt_seg_entries = ctx->opt_seg_entries;
     tmp.opt_reduce_scan = ctx->opt_reduce_scan;
@@ -840,6 +910,7 @@ void set_bases_device(mi355_msm_ctx* ctx, const void* d_affine, size_t n, size_t
   if (n >= (1ull << 31)) bad_arg("npoints %zu exceeds 2^31-1", n);
   ctx->pre_c = ctx->pre_windows = 0;
   ctx->nbases = 0;
+  ctx->anchor_sums.clear();   // sums of the previous bases
   ctx->fitted_chunk = 0;   // the plan (tables, window size) may change with the base set: fit the first chunk again
   ctx->te_active = false;
   ctx->te_fallback_streak = 0;
@@ -915,6 +986,7 @@ struct HostTail<Fp2El<F, NB>> {   // G2: the same code over Fp2
   using Pt = XyzzG64<F2_64>;
   static void set_inf(Pt& a) { sw64_set_inf(a); }
   static void add(Pt& a, const Pt& b) { sw64_add(fp2_64_of<F, NB>(), a, b); }
+  static void dbl(Pt& a) { sw64_dbl(fp2_64_of<F, NB>(), a); }
   static void fold(Pt& out, const XyzzT<Fe2>* sums, int windows, int c) { fold_windows64<F>(fp2_64_of<F, NB>(), out, sums, windows, c); }
   static void to_abi(uint8_t* out, const Pt& a) { sw64_to_abi(fp2_64_of<F, NB>(), out, a); }
 };
@@ -923,6 +995,7 @@ struct HostTail<FpEl<F>> {
   using Pt = Xyzz64;
   static void set_inf(Pt& a) { sw64_set_inf(a); }
   static void add(Pt& a, const Pt& b) { sw64_add(fp64_of<F>(), a, b); }
+  static void dbl(Pt& a) { sw64_dbl(fp64_of<F>(), a); }
   static void fold(Pt& out, const Xyzz* sums, int windows, int c) { fold_windows64<F>(fp64_of<F>(), out, sums, windows, c); }
   // (the Edwards kernels hold their points in the limb shape of TeFq: te.hpp)
   static bool fold_te(Pt& out, const Xyzz* sums, int windows, int c) {
@@ -994,7 +1067,8 @@ bool run_chunk_impl(mi355_msm_ctx* ctx, const uint32_t* d_scalars, size_t base0,
   }
   reserve_work(ctx, chunk_work_bytes(p, n, use_tables, sizeof(XyzzDev), carry != nullptr));
   const uint32_t table_stride = use_tables ? (uint32_t)ctx->nbases : 0u;
-  const PartPlan gp = part_plan((uint32_t)n, p.c, p.windows, use_tables ? p.levels : 1, (uint32_t)base0, table_stride, ctx->opt_assume_subgroup != 0);
+  const PartPlan gp = part_plan((uint32_t)n, p.c, p.windows, use_tables ? p.levels : 1, (uint32_t)base0, table_stride, ctx->opt_assume_subgroup != 0, p.anchor);
+  ctx->last_anchor = gp.anchor;
   const size_t nbuckets = (size_t)p.bucket_windows * p.half;
   if (ctx->pinned_bytes < p.windows * sizeof(XyzzDev)) {
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
@@ -1252,6 +1326,88 @@ bool run_chunk(mi355_msm_ctx* ctx, const uint32_t* d_scalars, size_t base0, size
   return true;
 }
 
+// ---- anchored window: the sum of the bases of a run, and its multiples (see choose_window_bits) ------------------------------------
+__global__ void __launch_bounds__(256) k_fill_scalar_one(uint4* __restrict__ scalars, size_t n) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;   // one 16-byte half of a 32-byte scalar
+  if (i < 2 * n) scalars[i] = make_uint4((i & 1) ? 0u : 1u, 0u, 0u, 0u);
+}
+
+// S = the sum of bases [0, n) (the ones not flagged infinite), by the pipeline itself: an MSM whose scalars are all 1, plain digits, in
+// chunks of at most 2^24 pairs that share one 512-MB scalar buffer.  Kept per context and n until the bases change.  The caller's stage
+// timings and counters are those of ITS run: the nested chunks leave no trace in them.
+template <class C>
+void anchor_sum_of_bases(mi355_msm_ctx* ctx, size_t n, hipStream_t st, typename HostTail<typename C::E>::Pt& S) {
+  using E = typename C::E;
+  using Pt = typename HostTail<E>::Pt;
+  static_assert(std::is_trivially_copyable_v<Pt>, "cached as bytes");
+  for (const auto& a : ctx->anchor_sums)
+    if (a.n == n && a.shift < 0) {
+      memcpy(&S, a.pt.data(), sizeof S);
+      return;
+    }
+  const auto t0 = std::chrono::steady_clock::now();
+  float ms[MI355_T_COUNT];
+  uint64_t info[8];
+  memcpy(ms, ctx->last_ms, sizeof ms);
+  memcpy(info, ctx->last_info, sizeof info);
+  const long mont = ctx->opt_scalars_montgomery;
+  const bool armed = ctx->anchor_armed;
+  const long inject = ctx->inject_alloc_failures;   // (a test hook aimed at the caller's chunks)
+  ctx->opt_scalars_montgomery = 0;
+  ctx->anchor_armed = false;
+  ctx->inject_alloc_failures = 0;
+  DevBuf ones;
+  auto restore = [&] {
+    ctx->opt_scalars_montgomery = mont;
+    ctx->anchor_armed = armed;
+    ctx->inject_alloc_failures = inject;
+    memcpy(ctx->last_ms, ms, sizeof ms);
+    memcpy(ctx->last_info, info, sizeof info);
+    ones.release();
+  };
+  try {
+    const size_t step = std::min(n, (size_t)1 << 24);
+    ones.reserve(step * 32);
+    hipLaunchKernelGGL(k_fill_scalar_one, dim3((unsigned)((2 * step + 255) / 256)), dim3(256), 0, st, ones.as<uint4>(), step);
+    HIP_OK(hipGetLastError());
+    HostTail<E>::set_inf(S);
+    for (size_t off = 0; off < n;) {
+      const bool tables_now = ctx->pre_c && (ctx->te_active || !ctx->sw_level0_only);
+      const size_t cn = fit_chunk(ctx, std::min(step, n - off), tables_now);
+      Pt part;
+      run_chunk<C>(ctx, ones.as<uint32_t>(), off, cn, st, part);
+      HostTail<E>::add(S, part);
+      off += cn;
+    }
+  } catch (...) {
+    restore();
+    throw;
+  }
+  restore();
+  if (ctx->anchor_sums.size() >= 12) ctx->anchor_sums.erase(ctx->anchor_sums.begin(), ctx->anchor_sums.begin() + 4);
+  mi355_msm_ctx::AnchorSum a{n, -1, std::vector<uint8_t>(sizeof S)};
+  memcpy(a.pt.data(), &S, sizeof S);
+  ctx->anchor_sums.push_back(std::move(a));
+  ctx->anchor_sums_computed++;
+  ctx->anchor_sum_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+
+// 2^shift x S (shift ~ 250 host doublings, ~0.15 ms: kept beside S)
+template <class C>
+void anchor_term(mi355_msm_ctx* ctx, size_t n, int shift, const typename HostTail<typename C::E>::Pt& S, typename HostTail<typename C::E>::Pt& out) {
+  using E = typename C::E;
+  for (const auto& a : ctx->anchor_sums)
+    if (a.n == n && a.shift == shift) {
+      memcpy(&out, a.pt.data(), sizeof out);
+      return;
+    }
+  out = S;
+  for (int i = 0; i < shift; i++) HostTail<E>::dbl(out);
+  mi355_msm_ctx::AnchorSum a{n, shift, std::vector<uint8_t>(sizeof out)};
+  memcpy(a.pt.data(), &out, sizeof out);
+  ctx->anchor_sums.push_back(std::move(a));
+}
+
 // Streams the scalar batches of a host-pointer run: batch b+1 is copied while batch b computes
 // (the reference's double-buffered batches, P1A 6block/cuda/pippenger_inf.cu:110-160; CMB MSM.cu:419-505), and the FIRST
 // batch -- whose copy nothing can hide -- is handed over in two pieces, 1/4 then 3/4, so that the first quarter is already
@@ -1287,6 +1443,28 @@ void run_device_t(mi355_msm_ctx* ctx, uint8_t* out, const uint32_t* d_scalars, s
   size_t max_chunk = ctx->opt_max_chunk ? (size_t)ctx->opt_max_chunk : ((size_t)1 << 26);
   ctx->chunk_cap = 0;
   const size_t out_bytes = 3 * 4 * E::WORDS;
+  // Anchored window: where the batch's window size has one (see choose_window_bits), the sum of bases [0, n) must be at hand before
+  // anything of this run is in flight -- computed now if this context has not run n pairs before.  Short of memory for that: plain digits.
+  typename HostTail<E>::Pt anchor_S;
+  struct AnchorScope {
+    mi355_msm_ctx* c;
+    ~AnchorScope() { c->anchor_armed = false; }
+  } anchor_scope{ctx};
+  ctx->anchor_armed = false;
+  ctx->anchor_sum_ms = 0;
+  if (batches && ctx->anchor_wanted(n)) {
+    const bool tables0 = ctx->pre_c && (ctx->te_active || !ctx->sw_level0_only);
+    if (anchor_window((int)ctx->plan(std::min(n, (size_t)1 << 26), tables0).c, ctx->scalar_bits(), ctx->opt_anchor == 2) != kNoAnchor) {
+      try {
+        anchor_sum_of_bases<C>(ctx, n, st, anchor_S);
+        ctx->anchor_armed = true;
+      } catch (const HipFailure& e) {
+        if (e.code != (int)hipErrorOutOfMemory) throw;
+        (void)hipStreamSynchronize(st);
+        release_work_buffers(ctx);
+      }
+    }
+  }
   // first piece of a host-scalar batch = 1/div of it.  Carried, with a merge pass per piece (XYZZ): 13 (1/13 + 3/13 + 9/13); carried onto
   // the stored buckets (twisted Edwards, round 6: a piece costs no merge): 26, a fourth piece and half the PCIe wait before the first
   // kernel (2^26: 112.1 -> 110.2 ms same-box, profiles/r06_ab_carry_in.txt); not carried: 4
@@ -1317,6 +1495,7 @@ void run_device_t(mi355_msm_ctx* ctx, uint8_t* out, const uint32_t* d_scalars, s
     // A batch that runs as several chunks carries one bucket array through them (BucketCarry): decided at its first chunk
     BucketCarry carry{};
     bool carried = false, allow_te = true;
+    uint32_t batch_anchor = kNoAnchor, batch_c = 0;   // the anchored window of the batch's chunks (all of them, or none)
     size_t reclaimed_at = (size_t)-1;   // chunk position at which the idle stateless contexts were last reclaimed
     for (size_t off = 0; off < n;) {
       // plan the chunk against the memory that is there (ML msm.cu:453-466 plans first, too) ...
@@ -1406,9 +1585,21 @@ void run_device_t(mi355_msm_ctx* ctx, uint8_t* out, const uint32_t* d_scalars, s
         ctx->fitted_tables = tables_now;
         ctx->fitted_c = fc;
       }
+      if (off == 0) {
+        batch_anchor = ctx->last_anchor;
+        batch_c = (uint32_t)ctx->last_info[0];
+      } else if (ctx->last_anchor != batch_anchor || (batch_anchor != kNoAnchor && (uint32_t)ctx->last_info[0] != batch_c)) {
+        throw HipFailure(-2, "mi355_msm: the chunks of a batch disagree about its anchored window (internal error)");
+      }
       HostTail<E>::add(total, part);
       off += cn;
       carry.index++;
+    }
+    if (batch_anchor != kNoAnchor) {
+      // every scalar's digit in the anchored window was taken relative to 2^(c-1): add 2^(c a + c - 1) x (sum of the bases)
+      typename HostTail<E>::Pt term;
+      anchor_term<C>(ctx, n, (int)(batch_c * batch_anchor + batch_c - 1), anchor_S, term);
+      HostTail<E>::add(total, term);
     }
     if (!allow_te) te_fell_back(ctx);
     if (!prefetched) prefetch();   // n == 0
@@ -1929,6 +2120,12 @@ RustError mi355_msm_set_option(mi355_msm_ctx* ctx, const char* key, long value) 
       ctx->opt_assume_subgroup = value != 0;
     } else if (k == "carry") {
       ctx->opt_carry = value != 0;
+    } else if (k == "anchor") {
+      // 1 (default): batches of 2^20 pairs and more end the signed-digit carry chain at the last full window where the window size
+      // leaves (almost) no bits above it, and the constant part rides on the sum of the bases (choose_window_bits); 0: plain digits
+      // (2: a test setting -- any batch size, any window size, gain or not)
+      if (value < 0 || value > 2) bad_arg("anchor %ld out of range [0, 2]", value);
+      ctx->opt_anchor = value;
     } else if (k == "first_piece_div") {
       if (value != 0 && (value < 2 || value > 64)) bad_arg("first_piece_div %ld out of range [2, 64]", value);
       ctx->opt_first_piece_div = value;
@@ -2023,8 +2220,8 @@ RustError mi355_msm_query(mi355_msm_ctx* ctx, const char* key, uint64_t* value) 
       //  the per-shard value (the largest, should the slices differ), not the sum over the shards)
       static const char* const kAll[] = {"twisted_edwards", "assume_subgroup", "carry"};
       static const char* const kMean[] = {"table_levels", "table_window_bits"};
-      static const char* const kFirst[] = {"precompute", "g2_paired", "guard_tail", "te_limb_bits"};
-      static const char* const kMax[] = {"bucket_windows", "l1_bits", "l1_bins", "group_passes", "top_split"};
+      static const char* const kFirst[] = {"precompute", "g2_paired", "guard_tail", "te_limb_bits", "anchor"};
+      static const char* const kMax[] = {"bucket_windows", "l1_bits", "l1_bins", "group_passes", "anchored_window", "anchor_sum_us"};
       auto in = [&](const char* const* set, size_t n) {
         for (size_t i = 0; i < n; i++)
           if (k == set[i]) return true;
@@ -2034,7 +2231,7 @@ RustError mi355_msm_query(mi355_msm_ctx* ctx, const char* key, uint64_t* value) 
         *value = all;
       } else if (in(kMean, 2)) {
         *value = sum / ctx->shards.size();
-      } else if (in(kFirst, 4) || in(kMax, 5)) {
+      } else if (in(kFirst, 5) || in(kMax, 6)) {
         uint64_t first = 0, mx = 0;
         for (size_t g = 0; g < ctx->shards.size(); g++) {
           uint64_t v = 0;
@@ -2047,7 +2244,7 @@ RustError mi355_msm_query(mi355_msm_ctx* ctx, const char* key, uint64_t* value) 
           if (g == 0) first = v;
           mx = std::max(mx, v);
         }
-        *value = in(kFirst, 4) ? first : mx;
+        *value = in(kFirst, 5) ? first : mx;
       } else {
         *value = sum;
       }
@@ -2063,6 +2260,22 @@ RustError mi355_msm_query(mi355_msm_ctx* ctx, const char* key, uint64_t* value) 
       *value = ctx->opt_assume_subgroup ? 1 : 0;
     else if (k == "carry")
       *value = ctx->opt_carry ? 1 : 0;
+    else if (k == "anchor")
+      *value = (uint64_t)ctx->opt_anchor;
+    else if (k == "anchored_window")   // of the most recent chunk: 1 + the window whose digits were taken relative to 2^(c-1); 0 = plain digits
+      *value = ctx->last_anchor == kNoAnchor ? 0 : (uint64_t)ctx->last_anchor + 1;
+    else if (k == "sorted_entries") {  // non-zero digits of the most recent chunk = its mixed additions (read back from the device: synchronises)
+      uint32_t v = 0;
+      if (ctx->part_totals.p) {
+        ensure_device(ctx);
+        HIP_OK(hipDeviceSynchronize());
+        HIP_OK(hipMemcpy(&v, ctx->part_totals.p, sizeof v, hipMemcpyDeviceToHost));
+      }
+      *value = v;
+    } else if (k == "anchor_sums")       // sums of bases computed for anchored windows since the context was created
+      *value = ctx->anchor_sums_computed;
+    else if (k == "anchor_sum_us")     // host wall time the most recent run spent on such a sum (0: it was at hand)
+      *value = (uint64_t)(ctx->anchor_sum_ms * 1000.0f);
     else if (k == "oom_backoffs")
       *value = ctx->oom_backoffs;
     else if (k == "debug_checks")   // invariant checks a -DMSM_DEBUG build has run on this context (always 0 in the product build)

@@ -111,6 +111,7 @@ struct StatelessLease {
         }
     }
     take(mi355_msm_create(&ctx, curve, device));
+    ctx->opt_anchor = 0;   // new bases with every call: the sum of the bases an anchored window needs would be computed every time
   }
   void keep() { ok = true; }   // the call went through: the context goes back to the pool instead of being destroyed
   ~StatelessLease() {

@@ -124,9 +124,14 @@ __device__ __forceinline__ uint32_t scalar_window(const uint32_t (&s)[8], uint32
   }
 }
 // the digit of window w: `u` = its c raw bits (scalar_window(st.s, w c) & wmask)
+//
+// `anchor` (wave-uniform: this window is PartPlan::anchor -- round 6, never together with FOLD): the carry chain ENDS here.  The window's
+// value v = bits + carry in [0, 2^c] is written as 2^(c-1) + s with s in [-2^(c-1), 2^(c-1)]: |s| fits the same buckets, nothing is
+// carried up, and the constant 2^(c-1) of EVERY scalar -- zero or not -- is a multiple of the plain sum of the bases that the engine
+// adds on the host (msm_engine.hip, "anchored window").  The windows above start a fresh chain on the raw top bits.
 template <bool FOLD>
 __device__ __forceinline__ void next_digit(ScalarDigits& st, uint32_t u, uint32_t c, uint32_t half, uint32_t wmask, bool flip, uint32_t rwin,
-                                           uint32_t& mag, bool& neg) {
+                                           uint32_t& mag, bool& neg, bool anchor = false) {
   if constexpr (FOLD) {
     const uint32_t sub = u + ((st.carry >> 1) & 1u);   // <= 2^c
     const bool borrow = flip && rwin < sub;
@@ -138,9 +143,15 @@ __device__ __forceinline__ void next_digit(ScalarDigits& st, uint32_t u, uint32_
     st.carry = (over ? 1u : 0u) | (borrow ? 2u : 0u);
   } else {
     const uint32_t v = u + st.carry;
-    neg = v > half;
-    mag = neg ? (1u << c) - v : v;
-    st.carry = neg ? 1u : 0u;
+    if (anchor) {
+      neg = v < half;
+      mag = neg ? half - v : v - half;
+      st.carry = 0;
+    } else {
+      neg = v > half;
+      mag = neg ? (1u << c) - v : v;
+      st.carry = neg ? 1u : 0u;
+    }
   }
 }
 
@@ -270,7 +281,7 @@ __global__ void __launch_bounds__(PART_THREADS) k_l1_hist(const uint32_t* __rest
     for (uint32_t w = 0; w < p.windows; w++) {
       uint32_t mag;
       bool neg;
-      next_digit<FOLD>(st, scalar_window(st.s, w * p.c) & wmask, p.c, p.half, wmask, flip, FOLD ? fr_window<FR>(w, p.c, wmask) : 0u, mag, neg);
+      next_digit<FOLD>(st, scalar_window(st.s, w * p.c) & wmask, p.c, p.half, wmask, flip, FOLD ? fr_window<FR>(w, p.c, wmask) : 0u, mag, neg, w == p.anchor);
       if (w < w_lo || w >= w_hi) continue;   // (block-uniform) another block of this tile counts that window
       bool dead = dead0;
       if (have && p.table_stride) dead = inf[l1_base_index(p, i, w)] != 0;
@@ -462,7 +473,7 @@ __global__ void __launch_bounds__(PART_THREADS) k_l1_scatter(const uint32_t* __r
         uint32_t mag;
         bool neg;
         next_digit<FOLD>(st[k], scalar_window(st[k].s, w * p.c) & wmask, p.c, p.half, wmask, ((alive >> (8 + k)) & 1) != 0,
-                         FOLD ? fr_window<FR>(w, p.c, wmask) : 0u, mag, neg);
+                         FOLD ? fr_window<FR>(w, p.c, wmask) : 0u, mag, neg, w == p.anchor);
       }
     }
   }
@@ -498,7 +509,7 @@ __global__ void __launch_bounds__(PART_THREADS) k_l1_scatter(const uint32_t* __r
       }
       uint32_t mag;
       bool neg;
-      next_digit<FOLD>(st[k], raw[k] & wmask, p.c, p.half, wmask, ((alive >> (8 + k)) & 1) != 0, rwin, mag, neg);
+      next_digit<FOLD>(st[k], raw[k] & wmask, p.c, p.half, wmask, ((alive >> (8 + k)) & 1) != 0, rwin, mag, neg, w == p.anchor);
       const uint32_t i = i0 + threadIdx.x + k * PART_THREADS;
       bool ok = ((alive >> k) & 1) && mag != 0;
       const uint32_t idx = l1_base_index(p, i, w);
@@ -863,7 +874,7 @@ __global__ void __launch_bounds__(256) k_dbg_count_digits(const uint32_t* __rest
       st.s[7] >>= p.c;
       uint32_t mag;
       bool neg;
-      next_digit<FOLD>(st, u, p.c, p.half, wmask, flip, FOLD ? fr_window<FR>(w, p.c, wmask) : 0u, mag, neg);
+      next_digit<FOLD>(st, u, p.c, p.half, wmask, flip, FOLD ? fr_window<FR>(w, p.c, wmask) : 0u, mag, neg, w == p.anchor);
       const bool dead = inf[l1_base_index(p, i, w)] != 0;
       if (mag != 0 && !dead) count++;
     }

@@ -52,7 +52,9 @@ struct PartPlan {
   uint32_t tiles_per_group;          // column-scan grouping
   uint32_t wgroups, wper;            // level-1 blocks per tile (each takes `wper` consecutive windows): fills the chip when tiles are few
   uint32_t fold;                     // 1: a scalar k in (r/2, r) is replaced by r - k with all its digits negated (load_scalar)
+  uint32_t anchor;                   // the window whose digit is taken relative to 2^(c-1) and ends the carry chain (next_digit); PART_NO_ANCHOR: none
 };
+constexpr uint32_t PART_NO_ANCHOR = 0xffffffffu;
 
 // Geometry of one generic pass.
 struct PassPlan {
@@ -67,9 +69,11 @@ inline uint32_t part_ceil_div(uint64_t a, uint64_t b) { return (uint32_t)((a + b
 
 // `levels` = precomputed table levels (0 or 1: none).  With k levels the windows g, g + G, g + 2G, ... (G = ceil(windows / k)) feed bucket
 // set g: yrrid's shape is k = 6, G = 2 (CMB PrecomputePoints.cu:10-39, MSM.cu:380-383); k >= windows is "one bucket set for all".
-inline PartPlan part_plan(uint32_t n, uint32_t c, uint32_t windows, uint32_t levels, uint32_t idx0, uint32_t table_stride, bool fold = false) {
+inline PartPlan part_plan(uint32_t n, uint32_t c, uint32_t windows, uint32_t levels, uint32_t idx0, uint32_t table_stride, bool fold = false,
+                          uint32_t anchor = 0xffffffffu) {
   PartPlan p{};
   p.fold = fold ? 1 : 0;
+  p.anchor = fold ? 0xffffffffu : anchor;
   p.n = n;
   p.c = c;
   p.windows = windows;

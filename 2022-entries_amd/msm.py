@@ -294,7 +294,7 @@ class MultiScalarMultContext:
     def query(self, key: str) -> int:
         """Context state: "twisted_edwards", "twisted_edwards_fallbacks", "twisted_edwards_demotions", "oom_backoffs", "chunk_cap",
         "device", "shards", "rccl_exchanges", "peer_stagings", "bases", "table_levels", "table_window_bits", "base_bytes", "assume_subgroup",
-        "carry", "precompute", "g2_paired", and the geometry of the most recent chunk: "bucket_windows", "l1_bits", "l1_bins", "group_passes"."""
+        "carry", "precompute", "g2_paired", "anchor", "anchored_window", "anchor_sums", "anchor_sum_us", and the geometry of the most recent chunk: "bucket_windows", "l1_bits", "l1_bins", "group_passes"."""
         v = ctypes.c_uint64(0)
         _check(self._lib.mi355_msm_query(self.context, key.encode(), ctypes.byref(v)))
         return int(v.value)

@@ -855,6 +855,10 @@ def main():
     geom = {k: ctx.query(k) for k in ("bucket_windows", "l1_bits", "l1_bins", "group_passes")} if not c_sharded else None
     g2_paired = ctx.query("g2_paired") if (cid >= 2 and not c_sharded) else None
     ctx_levels = ctx.query("table_levels")
+    # mixed additions of one accumulate launch = non-zero digits (the entry capacity windows * n counts windows that stay (almost) empty:
+    # the top window of an anchored plan); the anchored window itself, for the record
+    sorted_entries = ctx.query("sorted_entries") if not c_sharded else 0
+    anchored_window = ctx.query("anchored_window") if not c_sharded else 0
     te_limb_bits = ctx.query("te_limb_bits")   # 29: the Edwards kernels run on 13 x 29-bit limbs (337 multiply-adds per product), 28: 14 x 28 (378)
 
     # measurements that borrow the headline context (its bases ARE the workload's), then its ONE close
@@ -923,7 +927,7 @@ def main():
         # (574 each with the p0 = 1 shortcut of BLS12-377, 588 for BLS12-381), i.e. 20 per addition; one lane per point: 8 x 2 + 2 x (1 + 2/3).
         paired = bool(g2_paired and (g2_paired & 1))
         mads_per_add = {0: ((2359 if te_limb_bits == 29 else 2646) if ctx_te_path else 3416), 1: 3542, 2: 11480 if paired else 11088, 3: 11760 if paired else 11368}[cid]
-        adds_per_launch = tm["entries"]          # one mixed addition per sorted entry (zero digits are a ~1e-6 fraction)
+        adds_per_launch = sorted_entries or tm["entries"]   # one mixed addition per sorted entry
         mad_rate = mads_per_add * adds_per_launch / kern_s
         mad_peak = MAD_PEAK
         ms_all = sorted(s["ms_per_step"] for s in samples)
@@ -960,6 +964,8 @@ def main():
                                     + "), bases+scalars resident in HBM" if total_npow else
                                     f"{args.curve} MSM, 2^{args.npow} pairs per GPU, bases+scalars resident in HBM"),
                        "pairs_per_gpu": n, "window_bits": tm["window_bits"], "windows": tm["windows"],
+                       "anchored_window": (anchored_window - 1) if anchored_window else None,
+                       "mixed_additions_per_launch": adds_per_launch,
                        "lane_entries": tm["lane_entries"], "precompute": args.precompute, "table_levels": ctx_levels,
                        "group_law": "extended twisted Edwards (7M mixed add)" if ctx_te_path else "XYZZ (8M+2S mixed add)",
                        "g2_paired": g2_paired,

@@ -175,6 +175,17 @@ RustError mi355_msm_job_wait(mi355_msm_job* job);
  * generator's do.  A scalar k in (r/2, r) then runs as (r - k)(-P): the winners' top-bit trick (CMB ProcessSignedDigits.cu:10-20,
  * 123-128), one significant bit less, so BLS12-377 scalars tile 12 windows of 21 bits and the auto window size moves from 20 to 21
  * at 2^26 pairs (-5 % additions; below 2^25 pairs the window choice is left alone).  Off by default because arkworks' msm is exact for ANY curve point and this is not.
+ * "anchor" (default 1; 0 off; 2 = always, a test setting): the anchored window.  Signed digits carry, so where the window size leaves
+ * (almost) no scalar bits above the last full window -- BLS12-377: 253 = 11 x 23, 252 = 12 x 21 -- the window above it is still
+ * non-zero for 14-57 % of the scalars.  assume_subgroup removes those additions by an assumption; this removes them by arithmetic:
+ * the carry chain ENDS at the last full window (its value v in [0, 2^c] is taken as 2^(c-1) + s, |s| <= 2^(c-1): the same buckets)
+ * and the constant part, 2^(c a + c - 1) x (the plain sum of the bases of the run), is added on the host.  That sum is computed by
+ * the pipeline itself (an MSM with all scalars 1) the first time a context runs a given number of pairs -- ~1/12 of an MSM, once --
+ * and kept until set_bases.  Exact for ANY input (tests/test_gpu_anchor.py: non-canonical scalars, points outside the subgroup).
+ * Used for batches of >= 2^20 pairs, with "carry" on and "assume_subgroup" off, at the window sizes where it saves >= 1 % of the
+ * additions; 2^26 pairs of BLS12-377 G1 then run at c = 21 instead of 20 (-1.0 %; with tables -1..-2.5 %: profiles/r06_ab_anchor.txt).
+ * The price: a scalar of ZERO costs one addition (its digit in the anchored window is -2^(c-1)) instead of none -- a batch that is
+ * mostly zeros should set "anchor" = 0.  The stateless call never uses it (its bases change with every call).
  * "carry" (default 1): a batch that runs as several chunks (max_chunk, the memory budget, the pieces of a host-scalar batch) carries
  * ONE bucket array through them -- every chunk uses the window size of the whole batch and only the last one reduces; 0 = every
  * chunk reduces its own buckets and the partial sums are added on the host.  "first_piece_div" (default 13; 4 with carry = 0): the
@@ -198,7 +209,8 @@ RustError mi355_msm_set_option(mi355_msm_ctx* ctx, const char* key, long value);
  * (chunks repeated on the XYZZ path so far), "twisted_edwards_demotions" (two fallbacks in a row demote the base set to XYZZ
  * until the next set_bases), "oom_backoffs" (chunks restarted at half size after a device allocation failed -- after the idle
  * contexts of the stateless pool were given back and the same chunk retried), "debug_checks" (invariant checks a -DMSM_DEBUG
- * build has run; always 0 in this library), "chunk_cap",
+ * build has run; always 0 in this library), "chunk_cap", "anchor" (the option), "anchored_window" (1 + the anchored window of the most
+ * recent chunk, 0 = plain digits), "anchor_sums" (sums of bases computed so far), "anchor_sum_us" (host time the most recent run spent on one),
  * "device", "bases", "table_levels", "table_window_bits", "base_bytes" (device bytes held for the bases). */
 RustError mi355_msm_query(mi355_msm_ctx* ctx, const char* key, uint64_t* value);
 /* Per-stage device time (ms, HIP events on the launch stream) of the most recent run, summed over its chunks

@@ -1,6 +1,6 @@
 """Same-box A/B of ONE integer option of a context (mi355_msm_set_option): the values are interleaved round-robin over `reps`
 rounds so that clock drift hits all alike; every value's result bytes must equal the first one's.
-Usage: ab_option.py <option> [curve] [npow] [values] [reps] [window_bits]"""
+Usage: [AB_PRE=precompute=2] ab_option.py <option> [curve] [npow] [values] [reps] [window_bits]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -19,6 +19,9 @@ tile = torch.from_numpy(ea.generate_points(1 << 15, distinct=1 << 15, seed=1, cu
 bases = tile[:n].contiguous() if n <= (1 << 15) else tile.repeat(n >> 15, 1).contiguous()
 sc = bench.uniform_scalars(n, bench.R381_TOP if "381" in curve else bench.R377_TOP, dev, 7)
 ctx = ea.MultiScalarMultContext(curve)
+for kv in os.environ.get("AB_PRE", "").split(","):      # options that must be set before the bases, e.g. AB_PRE=precompute=2
+    if kv:
+        ctx.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 ctx.set_bases(bases)
 if wbits:
     ctx.set_option("window_bits", wbits)
@@ -45,6 +48,6 @@ print("%s 2^%d  c=%s windows=%s  (%d interleaved rounds; wall ms: median [min..m
 for m in masks:
     ts = sorted(acc[m])
     tm = stages[m]
-    print("%s=%-2d  %8.2f [%7.2f .. %7.2f]   accumulate %7.2f  merge %5.2f  bucket_reduce %6.2f  (digits %.2f sort %.2f)" % (
-        opt, m, ts[len(ts) // 2], ts[0], ts[-1], tm["accumulate"], tm["segreduce"], tm["bucket_reduce"], tm["digits"], tm["sort"]))
+    print("%s=%-2d  %8.2f [%7.2f .. %7.2f]   c=%d  accumulate %7.2f  merge %5.2f  bucket_reduce %6.2f  (digits %.2f sort %.2f)" % (
+        opt, m, ts[len(ts) // 2], ts[0], ts[-1], tm["window_bits"], tm["accumulate"], tm["segreduce"], tm["bucket_reduce"], tm["digits"], tm["sort"]))
 ctx.close()
