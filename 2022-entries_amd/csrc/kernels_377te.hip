@@ -22,6 +22,12 @@ hipError_t LaunchTe::accumulate(const uint2* entries, const uint32_t* n_real, ui
   return hipGetLastError();
 }
 
+hipError_t LaunchTe::sum_bases(const TeAffineDev* bases, const uint8_t* inf, uint32_t first, uint32_t n, uint32_t per_lane, SegOut out, uint32_t nlanes,
+                               uint32_t* flags, hipStream_t st) {
+  hipLaunchKernelGGL((k_sum_bases<G>), dim3(te_blocks(nlanes)), dim3(256), 0, st, bases, inf, first, n, per_lane, out, nlanes, flags);
+  return hipGetLastError();
+}
+
 hipError_t LaunchTe::segreduce(const XyzzDev* in_slots, const uint32_t* in_keys, uint32_t n_in, uint32_t K, SegOut out, uint32_t nlanes,
                                uint32_t quad_limit, uint32_t* flags, hipStream_t st) {
   if (nlanes <= quad_limit)

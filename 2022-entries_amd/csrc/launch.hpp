@@ -35,6 +35,9 @@ struct Launch {
                                      uint32_t quad_limit, hipStream_t st, bool paired = false);
   // carried buckets: total[b] += part[b] (k_bucket_merge)
   static hipError_t bucket_merge(XyzzDevT<El>* total, const XyzzDevT<El>* part, uint32_t n, hipStream_t st, bool paired = false);
+  // anchored window: one fragment per lane of the plain sum of bases [first, first + n) (k_sum_bases)
+  static hipError_t sum_bases(const AffineDevT<El>* bases, const uint8_t* inf, uint32_t first, uint32_t n, uint32_t per_lane, SegOutT<El> out,
+                              uint32_t nlanes, hipStream_t st);
 };
 
 // The throughput kernels of a G2 curve with two lanes per point (SwPairLaw, laws.hpp); kernels_<curve>p.hip.  E = Fp2El<F, NB>.
@@ -65,6 +68,8 @@ struct LaunchTe {
                                   uint32_t windows, uint32_t out_stride, XyzzDev* out_a, XyzzDev* out_x, uint32_t* flags, hipStream_t st);
   static hipError_t reduce_scan_step(const XyzzDev* in, const XyzzDev* in2, XyzzDev* out, uint32_t nb, uint32_t windows, uint32_t d, uint32_t mode,
                                      uint32_t quad_limit, uint32_t* flags, hipStream_t st);
+  static hipError_t sum_bases(const TeAffineDev* bases, const uint8_t* inf, uint32_t first, uint32_t n, uint32_t per_lane, SegOut out, uint32_t nlanes,
+                              uint32_t* flags, hipStream_t st);
   // (no bucket_merge: the later chunks of a carried batch accumulate straight onto the stored buckets -- SegOutT::carry_in)
 };
 

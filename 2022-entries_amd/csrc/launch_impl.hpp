@@ -43,6 +43,13 @@ hipError_t Launch<E>::accumulate(const uint2* entries, const uint32_t* n_real, u
 }
 
 template <class E>
+hipError_t Launch<E>::sum_bases(const AffineDevT<El>* bases, const uint8_t* inf, uint32_t first, uint32_t n, uint32_t per_lane, SegOutT<El> out,
+                                uint32_t nlanes, hipStream_t st) {
+  hipLaunchKernelGGL((k_sum_bases<SwLaw<E>>), dim3(launch_blocks(nlanes)), dim3(256), 0, st, bases, inf, first, n, per_lane, out, nlanes, (uint32_t*)nullptr);
+  return hipGetLastError();
+}
+
+template <class E>
 hipError_t Launch<E>::segreduce(const XyzzDevT<El>* in_slots, const uint32_t* in_keys, uint32_t n_in, uint32_t K, SegOutT<El> out,
                                 uint32_t nlanes, uint32_t quad_limit, hipStream_t st, bool paired) {
   if (nlanes <= quad_limit) {   // latency form: four lanes per addition (msm_kernels.hpp)

@@ -198,9 +198,13 @@ struct DevBuf {
   }
   void release() {
     if (guard) {
+      // The address range stays RESERVED for the life of the process (47 bits of address space outlast any test): a later buffer never
+      // lands on the addresses of a freed one.  Round 6: unmap + free + reserve + map of the SAME range within one process -- the small
+      // buffers of the anchored window's sum of bases, replaced by the run's own a moment later -- made kernels of the second context
+      // of a process fault ("write access to a read-only page") or return wrong sums under this mode and only under it: translations
+      // of the old mapping were still in use.  With the range kept, a stale access faults instead of landing somewhere.
       (void)hipMemUnmap(guard->va, guard->mapped);
       (void)hipMemRelease(guard->handle);
-      (void)hipMemAddressFree(guard->va, guard->va_bytes);
       delete guard;
       guard = nullptr;
     } else if (p) {
@@ -1327,14 +1331,68 @@ bool run_chunk(mi355_msm_ctx* ctx, const uint32_t* d_scalars, size_t base0, size
 }
 
 // ---- anchored window: the sum of the bases of a run, and its multiples (see choose_window_bits) ------------------------------------
-__global__ void __launch_bounds__(256) k_fill_scalar_one(uint4* __restrict__ scalars, size_t n) {
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;   // one 16-byte half of a 32-byte scalar
-  if (i < 2 * n) scalars[i] = make_uint4((i & 1) ? 0u : 1u, 0u, 0u, 0u);
+// S = the sum of bases [0, n) (the ones not flagged infinite): k_sum_bases leaves one fragment per lane of 32..512 bases, the fragment merge
+// of the pipeline adds them up into bucket 0, k_collect_sums brings it (and the Edwards failure flag) to the host, the host tail turns it
+// into a point.  ~n mixed additions: 7 ms at 2^26.  TE = true returns false when an addition hit a vanishing denominator (bases outside
+// the prime-order subgroup): the caller repeats on the XYZZ records.
+template <class C, bool TE>
+bool sum_bases_impl(mi355_msm_ctx* ctx, size_t n, hipStream_t st, typename HostTail<typename C::E>::Pt& S) {
+  using E = typename C::E;
+  using El = typename E::T;
+  using XyzzDev = XyzzDevT<El>;
+  using SegOut = SegOutT<El>;
+  constexpr uint32_t kSegK = 8;
+  const uint32_t kPerLane = (uint32_t)std::min<size_t>(512, std::max<size_t>(32, n >> 17));   // ~2^17 lanes: a chip's worth, whatever n
+  const uint32_t nlanes = ceil_div(n, kPerLane);
+  ctx->buckets.reserve(sizeof(XyzzDev));
+  for (int k = 0; k < 2; k++) {
+    ctx->slots[k].reserve(2 * (size_t)nlanes * sizeof(XyzzDev));
+    ctx->slot_keys[k].reserve(2 * (size_t)nlanes * sizeof(uint32_t));
+  }
+  if (ctx->pinned_bytes < 64 * sizeof(XyzzDev)) {
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    ctx->pinned_bytes = 64 * sizeof(XyzzDev);
+    HIP_OK(hipHostMalloc(&ctx->pinned, ctx->pinned_bytes, hipHostMallocDefault));
+  }
+  uint32_t* flags = ctx->flags.as<uint32_t>();
+  HIP_OK(hipMemsetAsync(ctx->buckets.p, 0, sizeof(XyzzDev), st));   // the empty-bucket marker: no base at all
+  SegOut so{ctx->buckets.as<XyzzDev>(), ctx->slots[0].as<XyzzDev>(), ctx->slot_keys[0].as<uint32_t>()};
+  if constexpr (TE)
+    HIP_OK(LaunchTe::sum_bases(ctx->te_bases.as<TeAffineDev>(), ctx->inf.as<uint8_t>(), 0, (uint32_t)n, kPerLane, so, nlanes, flags, st));
+  else
+    HIP_OK(Launch<E>::sum_bases(ctx->bases.as<AffineDevT<El>>(), ctx->inf.as<uint8_t>(), 0, (uint32_t)n, kPerLane, so, nlanes, st));
+  uint32_t n_in = 2 * nlanes;
+  for (int cur = 0;; cur ^= 1) {
+    const uint32_t nl = ceil_div(n_in, kSegK);
+    SegOut o{ctx->buckets.as<XyzzDev>(), ctx->slots[cur ^ 1].as<XyzzDev>(), ctx->slot_keys[cur ^ 1].as<uint32_t>()};
+    if constexpr (TE)
+      HIP_OK(LaunchTe::segreduce(ctx->slots[cur].as<XyzzDev>(), ctx->slot_keys[cur].as<uint32_t>(), n_in, kSegK, o, nl, ctx->quad_limit, flags, st));
+    else
+      HIP_OK(Launch<E>::segreduce(ctx->slots[cur].as<XyzzDev>(), ctx->slot_keys[cur].as<uint32_t>(), n_in, kSegK, o, nl, ctx->quad_limit, st, false));
+    if (nl == 1) break;
+    n_in = 2 * nl;
+  }
+  const uint32_t row_u4 = sizeof(XyzzDev) / 16;
+  hipLaunchKernelGGL(k_collect_sums, dim3((row_u4 + 255) / 256), dim3(256), 0, st, reinterpret_cast<const uint4*>(ctx->buckets.p), row_u4, row_u4, 1u,
+                     reinterpret_cast<uint4*>(ctx->pinned), TE ? flags : nullptr, TE ? ctx->h_flags : nullptr);
+  HIP_OK(hipGetLastError());
+  HIP_OK(hipStreamSynchronize(st));
+  const XyzzDev* hs = reinterpret_cast<const XyzzDev*>(ctx->pinned);
+  bool empty = true;
+  for (size_t k = 0; k < sizeof(XyzzDev); k++) empty = empty && reinterpret_cast<const uint8_t*>(hs)[k] == 0;
+  if (empty) {
+    HostTail<E>::set_inf(S);
+    return !TE || ctx->h_flags[1] == 0;
+  }
+  const XyzzT<El> sum = hs[0].p;
+  if constexpr (TE)
+    return ctx->h_flags[1] == 0 && HostTail<E>::fold_te(S, &sum, 1, 1);
+  else
+    HostTail<E>::fold(S, &sum, 1, 1);
+  return true;
 }
 
-// S = the sum of bases [0, n) (the ones not flagged infinite), by the pipeline itself: an MSM whose scalars are all 1, plain digits, in
-// chunks of at most 2^24 pairs that share one 512-MB scalar buffer.  Kept per context and n until the bases change.  The caller's stage
-// timings and counters are those of ITS run: the nested chunks leave no trace in them.
+// Kept per context and n until the bases change.
 template <class C>
 void anchor_sum_of_bases(mi355_msm_ctx* ctx, size_t n, hipStream_t st, typename HostTail<typename C::E>::Pt& S) {
   using E = typename C::E;
@@ -1346,44 +1404,11 @@ void anchor_sum_of_bases(mi355_msm_ctx* ctx, size_t n, hipStream_t st, typename 
       return;
     }
   const auto t0 = std::chrono::steady_clock::now();
-  float ms[MI355_T_COUNT];
-  uint64_t info[8];
-  memcpy(ms, ctx->last_ms, sizeof ms);
-  memcpy(info, ctx->last_info, sizeof info);
-  const long mont = ctx->opt_scalars_montgomery;
-  const bool armed = ctx->anchor_armed;
-  const long inject = ctx->inject_alloc_failures;   // (a test hook aimed at the caller's chunks)
-  ctx->opt_scalars_montgomery = 0;
-  ctx->anchor_armed = false;
-  ctx->inject_alloc_failures = 0;
-  DevBuf ones;
-  auto restore = [&] {
-    ctx->opt_scalars_montgomery = mont;
-    ctx->anchor_armed = armed;
-    ctx->inject_alloc_failures = inject;
-    memcpy(ctx->last_ms, ms, sizeof ms);
-    memcpy(ctx->last_info, info, sizeof info);
-    ones.release();
-  };
-  try {
-    const size_t step = std::min(n, (size_t)1 << 24);
-    ones.reserve(step * 32);
-    hipLaunchKernelGGL(k_fill_scalar_one, dim3((unsigned)((2 * step + 255) / 256)), dim3(256), 0, st, ones.as<uint4>(), step);
-    HIP_OK(hipGetLastError());
-    HostTail<E>::set_inf(S);
-    for (size_t off = 0; off < n;) {
-      const bool tables_now = ctx->pre_c && (ctx->te_active || !ctx->sw_level0_only);
-      const size_t cn = fit_chunk(ctx, std::min(step, n - off), tables_now);
-      Pt part;
-      run_chunk<C>(ctx, ones.as<uint32_t>(), off, cn, st, part);
-      HostTail<E>::add(S, part);
-      off += cn;
-    }
-  } catch (...) {
-    restore();
-    throw;
+  bool done = false;
+  if constexpr (std::is_same_v<C, Bls12_377_G1>) {
+    if (ctx->te_active) done = sum_bases_impl<C, true>(ctx, n, st, S);   // (a failure here is not counted as a fallback of a run)
   }
-  restore();
+  if (!done) sum_bases_impl<C, false>(ctx, n, st, S);
   if (ctx->anchor_sums.size() >= 12) ctx->anchor_sums.erase(ctx->anchor_sums.begin(), ctx->anchor_sums.begin() + 4);
   mi355_msm_ctx::AnchorSum a{n, -1, std::vector<uint8_t>(sizeof S)};
   memcpy(a.pt.data(), &S, sizeof S);

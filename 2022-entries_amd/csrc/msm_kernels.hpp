@@ -384,6 +384,46 @@ __global__ void __launch_bounds__(256, G::ACC_WAVES) k_accumulate_glds(const uin
 #undef MSM_Q_POP
 }
 
+// The plain sum of bases [first, first + n) that are not flagged infinite -- what an anchored window's constant part is a multiple of
+// (msm_engine.hip, "the anchored window").  Lane t adds its `per_lane` consecutive bases with the law's mixed addition and leaves ONE
+// fragment of key 0 in slot 2t; the fragment merge (k_segreduce) adds the fragments up into out.buckets[0].  Runs once per context
+// and number of pairs: no gather tricks, the next record is simply loaded before the current addition.
+template <class G>
+__global__ void __launch_bounds__(256, G::ACC_WAVES) k_sum_bases(const typename G::BaseDev* __restrict__ bases, const uint8_t* __restrict__ inf,
+                                                   uint32_t first, uint32_t n, uint32_t per_lane, SegOutT<typename G::T> out, uint32_t nlanes,
+                                                   uint32_t* __restrict__ flags) {
+  using E = typename G::E;
+  static_assert(G::LANES == 1, "one lane per point");
+  const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= nlanes) return;
+  typename E::Md md;
+  const uint64_t beg64 = (uint64_t)t * per_lane;
+  const uint32_t beg = beg64 < n ? (uint32_t)beg64 : n, end = (n - beg > per_lane) ? beg + per_lane : n;
+  bool fresh = true, bad = false;
+  XyzzT<typename G::T> acc;
+  G::set_identity(acc);
+  G::begin_run(acc);
+  typename G::Base p_n;
+  if (beg < end) p_n = G::from_dev(bases[first + beg]);
+  for (uint32_t i = beg; i < end; i++) {
+    const typename G::Base p = p_n;
+    const bool dead = inf[first + i] != 0;
+    if (i + 1 < end) p_n = G::from_dev(bases[first + i + 1]);
+    if (dead) continue;
+    G::madd(acc, p, false, fresh, md);
+    if (G::CHECKS) bad |= G::failed(acc);
+    fresh = false;
+  }
+  out.slot_keys[2 * (size_t)t + 1] = KEY_NONE;
+  if (fresh) {
+    out.slot_keys[2 * (size_t)t] = KEY_NONE;
+  } else {
+    G::store_pt(out.slots + 2 * (size_t)t, acc, 0);
+    out.slot_keys[2 * (size_t)t] = 0;
+  }
+  if (G::CHECKS && bad) flags[1] = 1;
+}
+
 // Merge run fragments: same walk over the slot sequence of the previous level (keys non-decreasing,
 // KEY_NONE = hole), full additions.  Recursion ends when one lane covers everything.
 template <class G>

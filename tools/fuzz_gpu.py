@@ -82,6 +82,8 @@ for case in range(cases):
         ctx.set_option("carry", 0); opts["carry"] = 0          # chunks reduce their own buckets (the default carries one bucket array)
     if special == "" and rng.random() < 0.3:
         ctx.set_option("assume_subgroup", 1); opts["fold"] = 1  # the generator's points are multiples of G: scalars above r/2 fold
+    if rng.random() < 0.5:
+        ctx.set_option("anchor", 2); opts["anchor"] = 2         # round 6: the anchored window at any size and window size (msm_engine.hip)
     if cid >= 2 and rng.random() < 0.7:
         # round 5: which G2 throughput kernels run two lanes per point (csrc/fp2pair.hpp); quad_limit = 0 sends the merge and scan
         # launches of these small inputs through them at all
