@@ -104,7 +104,18 @@ for f in glob.glob(os.path.join(prof, "stats", "**", "*kernel_trace.csv"), recur
     if d:
         kern_ms = sum(d) / len(d)
 n = 1 << CFG["npow"]
+# the plan of the profiled run (bench line of the kernel-trace pass): window size, windows and -- since the anchored window, whose top
+# window stays (almost) empty -- the number of mixed additions of one launch as the device counted them
+cfg_line = None
+sb = os.path.join(prof, "stats_bench.json")
+if os.path.exists(sb):
+    lines = [ln for ln in open(sb).read().splitlines() if ln.startswith("{")]
+    if lines:
+        cfg_line = json.loads(lines[-1])["config"]
+        CFG["c"], CFG["windows"] = cfg_line["window_bits"], cfg_line["windows"]
 entries = CFG["windows"] * n * (1 - 2.0 ** -CFG["c"])     # non-zero digits
+if cfg_line and cfg_line.get("mixed_additions_per_launch"):
+    entries = float(cfg_line["mixed_additions_per_launch"])
 fetch_raw = (c.get("FETCH_SIZE") or 0) * 1024.0
 write_raw = (c.get("WRITE_SIZE") or 0) * 1024.0
 # what the launch has to read, by shape: one base record per entry, the sorted entries (8 B each; a lane that takes one entry
