@@ -907,6 +907,8 @@ bool build_tables_te_streamed(mi355_msm_ctx* ctx, const uint8_t* d_raw, size_t n
   return true;
 }
 
+void anchor_prepare(mi355_msm_ctx* ctx, size_t n, hipStream_t st);   // (below, with the anchored window's sum of bases)
+
 void set_bases_device(mi355_msm_ctx* ctx, const void* d_affine, size_t n, size_t stride) {
   ensure_device(ctx);
   const size_t min_stride = 2 * coord_bytes(ctx->curve) + (ctx->bases_serialized ? 0 : 1);
@@ -958,6 +960,8 @@ void set_bases_device(mi355_msm_ctx* ctx, const void* d_affine, size_t n, size_t
     if (ctx->curve == MI355_BLS12_377_G1 && ctx->opt_twisted_edwards && !te_done) build_te(ctx, n, ctx->own_stream);
   }
   ctx->nbases = n;
+  // the sum of all bases, where a run over all of them would use an anchored window: here, in the (untimed) init, not in the first run
+  if (n) anchor_prepare(ctx, n, ctx->own_stream);
 }
 
 // ---- the host tail (window fold, chunk sums, normalisation) -----------------------------------------------------------
@@ -1417,6 +1421,31 @@ void anchor_sum_of_bases(mi355_msm_ctx* ctx, size_t n, hipStream_t st, typename 
   ctx->anchor_sum_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }
 
+// Whether a run over bases [0, n) would use an anchored window, and if so its sum of bases (from the cache, or computed now).  Short of
+// memory for the handful of slots that takes: false, and the run uses plain digits.
+template <class C>
+bool anchor_ready(mi355_msm_ctx* ctx, size_t n, hipStream_t st, typename HostTail<typename C::E>::Pt& S) {
+  if (!ctx->anchor_wanted(n)) return false;
+  const bool tables0 = ctx->pre_c && (ctx->te_active || !ctx->sw_level0_only);
+  if (anchor_window((int)ctx->plan(std::min(n, (size_t)1 << 26), tables0).c, ctx->scalar_bits(), ctx->opt_anchor == 2) == kNoAnchor) return false;
+  try {
+    anchor_sum_of_bases<C>(ctx, n, st, S);
+    return true;
+  } catch (const HipFailure& e) {
+    if (e.code != (int)hipErrorOutOfMemory) throw;
+    (void)hipStreamSynchronize(st);
+    release_work_buffers(ctx);
+    return false;
+  }
+}
+void anchor_prepare(mi355_msm_ctx* ctx, size_t n, hipStream_t st) {
+  with_curve(ctx->curve, [&]<class C>() {
+    typename HostTail<typename C::E>::Pt S;
+    (void)anchor_ready<C>(ctx, n, st, S);
+  });
+  ctx->anchor_sum_ms = 0;
+}
+
 // 2^shift x S (shift ~ 250 host doublings, ~0.15 ms: kept beside S)
 template <class C>
 void anchor_term(mi355_msm_ctx* ctx, size_t n, int shift, const typename HostTail<typename C::E>::Pt& S, typename HostTail<typename C::E>::Pt& out) {
@@ -1477,19 +1506,7 @@ void run_device_t(mi355_msm_ctx* ctx, uint8_t* out, const uint32_t* d_scalars, s
   } anchor_scope{ctx};
   ctx->anchor_armed = false;
   ctx->anchor_sum_ms = 0;
-  if (batches && ctx->anchor_wanted(n)) {
-    const bool tables0 = ctx->pre_c && (ctx->te_active || !ctx->sw_level0_only);
-    if (anchor_window((int)ctx->plan(std::min(n, (size_t)1 << 26), tables0).c, ctx->scalar_bits(), ctx->opt_anchor == 2) != kNoAnchor) {
-      try {
-        anchor_sum_of_bases<C>(ctx, n, st, anchor_S);
-        ctx->anchor_armed = true;
-      } catch (const HipFailure& e) {
-        if (e.code != (int)hipErrorOutOfMemory) throw;
-        (void)hipStreamSynchronize(st);
-        release_work_buffers(ctx);
-      }
-    }
-  }
+  if (batches) ctx->anchor_armed = anchor_ready<C>(ctx, n, st, anchor_S);
   // first piece of a host-scalar batch = 1/div of it.  Carried, with a merge pass per piece (XYZZ): 13 (1/13 + 3/13 + 9/13); carried onto
   // the stored buckets (twisted Edwards, round 6: a piece costs no merge): 26, a fourth piece and half the PCIe wait before the first
   // kernel (2^26: 112.1 -> 110.2 ms same-box, profiles/r06_ab_carry_in.txt); not carried: 4

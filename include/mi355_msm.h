@@ -180,8 +180,8 @@ RustError mi355_msm_job_wait(mi355_msm_job* job);
  * non-zero for 14-57 % of the scalars.  assume_subgroup removes those additions by an assumption; this removes them by arithmetic:
  * the carry chain ENDS at the last full window (its value v in [0, 2^c] is taken as 2^(c-1) + s, |s| <= 2^(c-1): the same buckets)
  * and the constant part, 2^(c a + c - 1) x (the plain sum of the bases of the run), is added on the host.  That sum is computed by
- * the pipeline itself (an MSM with all scalars 1) the first time a context runs a given number of pairs -- ~1/12 of an MSM, once --
- * and kept until set_bases.  Exact for ANY input (tests/test_gpu_anchor.py: non-canonical scalars, points outside the subgroup).
+ * the library itself (k_sum_bases + the fragment merge: ~n mixed additions, 8 ms at 2^26) in set_bases for runs over all the bases, on
+ * the first run of any other length, and kept until the next set_bases.  Exact for ANY input (tests/test_gpu_anchor.py: non-canonical scalars, points outside the subgroup).
  * Used for batches of >= 2^20 pairs, with "carry" on and "assume_subgroup" off, at the window sizes where it saves >= 1 % of the
  * additions; 2^26 pairs of BLS12-377 G1 then run at c = 21 instead of 20 (-1.0 %; with tables -1..-2.5 %: profiles/r06_ab_anchor.txt).
  * The price: a scalar of ZERO costs one addition (its digit in the anchored window is -2^(c-1)) instead of none -- a batch that is
