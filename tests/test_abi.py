@@ -163,3 +163,19 @@ def test_bench_telemetry_never_raises_without_a_gpu():
     probe = bench.ark_ec_probe(10)
     assert probe["available"] in (False, True) and ("probe" in probe or "error" in probe or probe.get("kind") == "ark-ec")
     assert len(bench.kernel_source_sha16()) == 16
+
+
+def test_window_sizes_the_anchored_window_moves(ea):
+    """The window model with the anchored window (csrc/msm_engine.hip anchor_min_c; measured: profiles/r06_ab_anchor.txt, guarded on the GPU by
+    tests/test_gpu_window_model.py): BLS12-377 moves only to c = 21 (252 = 12 x 21) -- 2^26 pairs --, never to c = 18 (measured to lose at
+    2^23 and 2^24); BLS12-381 G1 takes c = 17 (255 = 15 x 17) from 2^22 to 2^23; BLS12-381 G2 and everything below 2^20 pairs stay as they were."""
+    assert ea.plan(1 << 26, "bls12_377_g1")["window_bits"] == 21
+    assert ea.plan(1 << 26, "bls12_377_g2")["window_bits"] == 21
+    assert ea.plan(1 << 24, "bls12_377_g1")["window_bits"] == 20
+    assert ea.plan(1 << 23, "bls12_377_g1")["window_bits"] == 17
+    assert ea.plan(1 << 22, "bls12_381_g1")["window_bits"] == 17
+    assert ea.plan(1 << 23, "bls12_381_g1")["window_bits"] == 17
+    assert ea.plan(1 << 24, "bls12_381_g1")["window_bits"] == 20
+    assert ea.plan(1 << 26, "bls12_381_g1")["window_bits"] == 20
+    assert ea.plan(1 << 22, "bls12_381_g2")["window_bits"] == 16
+    assert ea.plan((1 << 20) - 1, "bls12_381_g1")["window_bits"] == ea.plan((1 << 20) - 1, "bls12_381_g2")["window_bits"]
