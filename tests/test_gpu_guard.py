@@ -4,7 +4,9 @@ k_accumulate_glds refills its entry queue by whole 16-byte pieces past a lane's 
 next lane, or to the 64 bytes of slack behind the buffer", csrc/msm_kernels.hpp) and its LDS-DMA gathers fetch record 0 for idle
 lanes; the grouping kernels prefetch the next tile.  With MI355_MSM_GUARD_TAIL=1 the library places every device buffer so that it
 ENDS at the end of its mapping and leaves the following address range reserved but unmapped (HIP virtual-memory API, `DevBuf` in
-csrc/msm_engine.hip): an access beyond a buffer's last 16-byte-rounded byte is then a GPU memory fault that kills the process.  The
+csrc/msm_engine.hip; a freed buffer's address range stays reserved for the life of the process, so no later buffer is ever mapped
+onto addresses the device may still hold translations for -- round 6, tools/guard_repro.py): an access beyond a buffer's last
+16-byte-rounded byte is then a GPU memory fault that kills the process.  The
 plans below are the ones VERDICT r4 asked for -- n in {1, 63, 8191, 8193, 2^20 + 1}, lane_entries in {auto, 4, 512}, every curve -- plus
 the table, carried-chunk, folded-scalar, one-lane G2 and stateless paths; each runs in a child process (the mode is read once per
 process) and must return the oracle's bytes.  Reference counterpart: the disabled self-check of CMB Partition4096.cu:419-432; device
