@@ -1490,8 +1490,6 @@ template <class C>
 void run_device_t(mi355_msm_ctx* ctx, uint8_t* out, const uint32_t* d_scalars, size_t n, size_t batches, size_t dev_batch_pairs,
                   hipStream_t st, const HostBatches* hb) {
   using E = typename C::E;
-  using Xyzz = XyzzT<typename E::T>;
-  typename E::Md md;
   // An allocation failure caps the chunks of THIS run only (one transient event -- fragmentation, another tenant's spike --
   // must not cost every later MSM an extra bucket reduction): the next run plans against the memory that is free then.
   size_t max_chunk = ctx->opt_max_chunk ? (size_t)ctx->opt_max_chunk : ((size_t)1 << 26);
