@@ -214,3 +214,21 @@ def test_default_setting_at_a_megapair(ea, oracle):
         assert ctx.run(sc)[0] == exp and ctx.query("anchored_window") == 0
         print(f"{NAMES[cid]} n=2^20+3: anchor on -> c={c_on}, anchored window {a_on}; off -> c={ctx.last_timings()['window_bits']}")
         ctx.close()
+
+
+def test_sharded_context_keeps_one_sum_per_shard(ea, oracle):
+    """A sharded context (mi355_msm_create_sharded; here three logical shards on one device) anchors shard by shard: every shard holds the
+    sum of ITS slice of the bases, computed in set_bases; the partial points fold to the oracle's bytes."""
+    n = 20011
+    for cid in (0, 1):
+        bases = ea.generate_points(n, distinct=333, seed=90 + cid, curve=NAMES[cid])
+        sc = _scalars(cid, n, 17 + cid)
+        exp = oracle_msm_np(oracle, cid, bases, sc, n)
+        ctx = ea.MultiScalarMultContext(NAMES[cid], devices=[0, 0, 0])
+        ctx.set_option("anchor", 2)
+        ctx.set_bases(bases)
+        assert ctx.query("anchor_sums") == 3            # in set_bases: one per shard
+        assert ctx.run(sc)[0] == exp and ctx.query("anchored_window") > 0 and ctx.query("anchor_sums") == 3
+        ctx.set_option("force_peer_staging", 1)
+        assert ctx.run(sc)[0] == exp
+        ctx.close()
