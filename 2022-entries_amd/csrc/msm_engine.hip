@@ -465,6 +465,38 @@ struct mi355_msm_ctx {
     // (capped at 512 since round 3, 256 before: the accumulation takes the same time for 128..1024 entries per lane, the fragment
     //  merge halves with the lane count -- 2^26: 109.0 -> 108.5 ms, 2^25: 57.0 -> 56.8, BLS12-381 flat; profiles/r03_ab_lane_entries.txt)
     uint32_t K = opt_lane_entries ? (uint32_t)opt_lane_entries : (uint32_t)std::min<uint64_t>(512, k_auto);
+    // Block generations (round 6, tools/rounds_probe.py, profiles/r06_ab_lane_groups.txt).  The dispatcher hands the 256 CUs one block each
+    // and the blocks of such a group run in step, so the accumulation takes ceil(working blocks / 256) x (one group's time): with the
+    // pair count varied at K = 512 the BLS12-377 launch steps by 3.4 ms every 256 blocks and is flat in between (22 groups 76.0 ms, 23
+    // 79.3-79.5, 24 82.7-82.8, 25 85.9).  2^26 pairs at c = 20 are 26.00 groups by luck (13 n / (512 x 256 lanes) / 256); the anchored
+    // c = 21 is 24.29 -- a 25th generation for a third of a group.  So: the K nearest to the rule's whose expected working blocks fill their
+    // last group to >= 98.5 % (here 520: 23.91 groups; 102.92 -> 101.27 ms same-box).  Working blocks = expected non-zero digits of uniform
+    // canonical scalars / lanes of a block (128 where two hardware lanes share a point).  No safety margin on purpose: the power-of-two sizes
+    // sit EXACTLY on a whole number of groups (13 x 2^26 / 2^25 = 26), the real count can only be below that capacity, and moving them
+    // off it was measured to lose (BLS12-381 2^26: 132.5 -> 134.5 ms at K = 520).
+    if (!opt_lane_entries && !opt_assume_subgroup && K >= 64) {
+      double plain, anchored;
+      eff_windows(scalar_bits(), (int)p.c, plain, anchored);
+      // (a plan made outside a run -- mi355_msm_plan, the chunk fit -- expects the anchored window wherever a run would use it)
+      const bool anchor_expected = (anchor_armed || anchor_wanted(n)) && anchor_window((int)p.c, scalar_bits(), opt_anchor == 2) != kNoAnchor;
+      const double adds = (anchor_expected ? anchored : plain) * (double)n;
+      const double per_group = ((curve == MI355_BLS12_377_G2 || curve == MI355_BLS12_381_G2) && (opt_g2_paired & 1) ? 128.0 : 256.0) * 256.0;
+      auto fill = [&](long k) {
+        const double g = adds / ((double)k * per_group);
+        return g / std::ceil(g);
+      };
+      if (adds / ((double)K * per_group) >= 6.0) {
+        long best = (long)K;
+        double best_fill = fill(best);
+        for (long step = 8; step <= 96 && best_fill < 0.985; step += 8)
+          for (long k : {(long)K - step, (long)K + step})
+            if (k >= 64 && fill(k) > best_fill + 0.004) {
+              best = k;
+              best_fill = fill(k);
+            }
+        K = (uint32_t)best;
+      }
+    }
     p.K = K >= 8 ? (K + 7) & ~7u : (K + 3) & ~3u;   // a lane's entries start on a 64-byte boundary (k_accumulate_glds refills its entry queue by whole sectors)
     p.nlanes = ceil_div(p.entries, p.K);
     p.segK = opt_seg_entries >= 4 ? (uint32_t)opt_seg_entries : (p.entries < (2u << 20) ? 4 : 8);   // small inputs: shallower levels (-1..-3 %)

@@ -350,7 +350,9 @@ __global__ void __launch_bounds__(256, G::ACC_WAVES) k_accumulate_glds(const uin
       if (key != cur) {
         const bool lane_first = cur == KEY_NONE;
         if (cur != KEY_NONE) {
+#ifndef MSM_ACC_NO_FLUSH   // A/B only (profiles/r06_ab_flush.txt): defined = a finished run is not stored (wrong sums): what the bucket stores cost
           seg_flush<G>(out, t, nlanes, cur, acc, first, false, half);
+#endif
           first = false;
         }
         cur = key;

@@ -14,9 +14,9 @@ masks = [int(x) for x in (sys.argv[3] if len(sys.argv) > 3 else "0,1").split(","
 reps = int(sys.argv[4]) if len(sys.argv) > 4 else 5
 wbits = int(sys.argv[5]) if len(sys.argv) > 5 else 0
 dev = torch.device("cuda", 0)
-n = 1 << npow
+n = int(os.environ.get("AB_N", 1 << npow))          # AB_N: a size that is not a power of two
 tile = torch.from_numpy(ea.generate_points(1 << 15, distinct=1 << 15, seed=1, curve=curve)).to(dev)
-bases = tile[:n].contiguous() if n <= (1 << 15) else tile.repeat(n >> 15, 1).contiguous()
+bases = tile[:n].contiguous() if n <= (1 << 15) else tile.repeat((n >> 15) + 1, 1)[:n].contiguous()
 sc = bench.uniform_scalars(n, bench.R381_TOP if "381" in curve else bench.R377_TOP, dev, 7)
 ctx = ea.MultiScalarMultContext(curve)
 for kv in os.environ.get("AB_PRE", "").split(","):      # options that must be set before the bases, e.g. AB_PRE=precompute=2
@@ -44,7 +44,7 @@ for r in range(reps):
         acc[m].append((time.perf_counter() - t0) * 1e3)
         assert out == ref
         stages[m] = ctx.last_timings()
-print("%s 2^%d  c=%s windows=%s  (%d interleaved rounds; wall ms: median [min..max])" % (curve, npow, stages[masks[0]]["window_bits"], stages[masks[0]]["windows"], reps))
+print("%s 2^%d (n = %d)  c=%s windows=%s  (%d interleaved rounds; wall ms: median [min..max])" % (curve, npow, n, stages[masks[0]]["window_bits"], stages[masks[0]]["windows"], reps))
 for m in masks:
     ts = sorted(acc[m])
     tm = stages[m]
