@@ -652,6 +652,8 @@ def quoted_pmc(E, tm, te_path, total_npow):
         plan_then = dict(pmc.get("plan") or {})
         if E.cid >= 2 and plan_then.get("lanes") == 2 * plan_now["lanes"]:
             plan_then["lanes"] = plan_now["lanes"]       # (rocprof counts hardware lanes: two per walking lane in the paired G2 kernels)
+        if plan_then.get("lanes") == -(-plan_now["lanes"] // 256) * 256:
+            plan_then["lanes"] = plan_now["lanes"]       # (rocprof reports the grid: whole blocks of 256 threads)
         if pmc.get("kernel_source_sha16") == sha and plan_then != plan_now:
             traffic_from = f"not quoted: {pmc_rel} was measured under the plan {pmc.get('plan')}, this run uses {plan_now}"
         elif pmc.get("kernel_source_sha16") == sha:
