@@ -475,6 +475,7 @@ struct mi355_msm_ctx {
     // sit EXACTLY on a whole number of groups (13 x 2^26 / 2^25 = 26), the real count can only be below that capacity, and moving them
     // off it was measured to lose (BLS12-381 2^26: 132.5 -> 134.5 ms at K = 520).
     if (!opt_lane_entries && !opt_assume_subgroup && K >= 64) {
+      K = (K + 7) & ~7u;   // (the candidates are the values a plan can have: multiples of 8, see below)
       double plain, anchored;
       eff_windows(scalar_bits(), (int)p.c, plain, anchored);
       // (a plan made outside a run -- mi355_msm_plan, the chunk fit -- expects the anchored window wherever a run would use it)
