@@ -160,6 +160,8 @@ RustError mi355_msm_job_wait(mi355_msm_job* job);
  * 86 GB, k = 3 107 ms / 47 GB, no tables 108 ms / 21.5 GB.
  * Tuning knobs ("window_bits" 2..24, "lane_entries", "max_chunk" <= 2^27, "seg_entries" >= 4, "reduce_log_chunk" /
  * "reduce_log_chunk0" 1..7: bucket-reduction chunk sizes on all / the first level); 0 restores the automatic choice.
+ * ("lane_entries" = 0: 2^20 lanes up to 2^25 pairs, then ~512 entries per lane -- fitted so that the working blocks of the accumulate
+ * launch fill their last generation of 256 blocks, one per CU: the launch takes ceil(blocks / 256) generations, profiles/r06_ab_lane_groups.txt.)
  * "reduce_scan" = 0 keeps the bucket reduction on the recursive chunked scheme only (default: its tail is a parallel scan);
  * "reduce_scan_log" 6..18 = log2 of the elements per window at which the scan takes over (default 12).
  * "quad_limit" (per context, default 2^18): merge / scan launches of at most that many additions spread each
